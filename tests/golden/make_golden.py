@@ -1,0 +1,364 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by importing and running the LGAR-py reference itself.
+
+Runs ONLY in the build container (needs /root/reference); the reference never travels.
+Only the numeric fixtures this script emits (tests/golden/*.npz) are committed.
+
+Recipe: a stub `omegaconf.DictConfig` (tests/golden/_refstub), the reference's
+own YAML constants assembled with PyYAML, the agent's time derivations
+(/root/reference/dpLGAR/agents/DifferentiableLGAR.py:35-52) and the agent's call sequence
+`model(x[i]); mass_balance.change_mass(model)` (:117-125) minus its sleep.
+
+Usage:  python tests/golden/make_golden.py [case ...]     (no args = all cases, in parallel)
+"""
+import os
+import sys
+import tempfile
+import time
+import traceback
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+sys.path.insert(0, os.path.join(HERE, "_refstub"))
+sys.path.insert(0, REF)
+sys.dont_write_bytecode = True
+
+import numpy as np
+import torch
+import yaml
+
+FREC = 16  # front slots recorded per step
+
+# P-1..3 soils (data/utils.py:123-125,146-148,170-172 and data/vG_default_params.dat:14-16)
+PHIL = dict(
+    alpha=[0.0031297, 0.0083272, 0.0037454],
+    n=[1.6858, 1.299, 1.6151],
+    ksat=[0.45, 0.07, 0.45],
+    theta_e=[0.4513, 0.4773, 0.4617],
+    theta_r=[0.0648, 0.0831, 0.0668],
+    thickness=[44.0, 131.0, 25.0],
+)
+# B-1..3 soils (table rows 15-17)
+BUSH = dict(
+    alpha=[0.009567, 0.005288, 0.004467],
+    n=[1.3579, 1.5276, 1.4585],
+    ksat=[0.07, 0.02, 0.2],
+    theta_e=[0.4481, 0.4760, 0.4782],
+    theta_r=[0.0649, 0.0672, 0.0823],
+    thickness=[44.0, 131.0, 25.0],
+)
+# generic textures: silt-loam / loam / clay-loam (table rows 11, 2, 1)
+GENERIC = dict(
+    alpha=[0.01, 0.01, 0.02],
+    n=[1.66, 1.47, 1.42],
+    ksat=[0.756, 0.504, 0.3348],
+    theta_e=[0.44, 0.40, 0.44],
+    theta_r=[0.07, 0.06, 0.08],
+    thickness=[30.0, 80.0, 90.0],
+)
+
+
+def _fixed_forcing_csv(path, tmpdir):
+    """read_df wants .csv with a `Time` column; synth files have `#Time` + blank tail lines."""
+    with open(path) as f:
+        lines = [ln for ln in f.read().splitlines() if ln.strip()]
+    lines[0] = lines[0].lstrip("#")
+    out = os.path.join(tmpdir, os.path.basename(path).rsplit(".", 1)[0] + "_fixed.csv")
+    with open(out, "w") as f:
+        f.write("\n".join(lines) + "\n")
+    return out
+
+
+def _write_soil_dat(soil, tmpdir):
+    out = os.path.join(tmpdir, "soil.dat")
+    with open(out, "w") as f:
+        f.write("Texture\ttheta_r\ttheta_e\talpha(cm^-1)\tn\tm\tKs(cm/h)\n")
+        # row 0 is a dummy: the reference looks textures up at soil_type-1 (GlobalParams.py:120), so types start at 1
+        f.write('"dummy"\t0.1\t0.46\t0.01\t1.25\t0.2\t0.612\n')
+        for i in range(len(soil["alpha"])):
+            f.write(
+                '"L%d"\t%r\t%r\t%r\t%r\t%r\t%r\n'
+                % (i, soil["theta_r"][i], soil["theta_e"][i], soil["alpha"][i], soil["n"][i],
+                   1.0 - 1.0 / soil["n"][i], soil["ksat"][i])
+            )
+    return out
+
+
+def build_cfg(forcing_csv, soil_dat, soil, pdm, subcycle_s, forcing_res_s, endtime_h, initial_psi=2000.0):
+    from omegaconf import DictConfig
+
+    root = yaml.safe_load(open(os.path.join(REF, "dpLGAR/config.yaml")))
+    data = yaml.safe_load(open(os.path.join(REF, "dpLGAR/data/config/Phillipsburg.yaml")))
+    models = yaml.safe_load(open(os.path.join(REF, "dpLGAR/models/config/shorter_subcycle.yaml")))
+    cfg = DictConfig(
+        dict(device="cpu", constants=root["constants"], conversions=root["conversions"], data=data, models=models)
+    )
+    L = len(soil["alpha"])
+    cfg.data.forcing_file = forcing_csv
+    cfg.data.soil_params_file = soil_dat
+    cfg.data.layer_soil_type = list(range(1, L + 1))
+    cfg.data.layer_thickness = list(soil["thickness"])
+    cfg.data.ponded_depth_max = pdm
+    cfg.data.initial_psi = initial_psi
+    cfg.models.subcycle_length = subcycle_s
+    cfg.models.forcing_resolution = forcing_res_s
+    cfg.models.endtime = endtime_h
+    # agents/DifferentiableLGAR.py:35-52, verbatim derivations
+    cfg.models.endtime_s = cfg.models.endtime * cfg.conversions.hr_to_sec
+    cfg.models.subcycle_length_h = cfg.models.subcycle_length * (1 / cfg.conversions.hr_to_sec)
+    cfg.models.forcing_resolution_h = cfg.models.forcing_resolution / cfg.conversions.hr_to_sec
+    cfg.models.time_per_step = cfg.models.forcing_resolution_h * cfg.conversions.hr_to_sec
+    cfg.models.nsteps = int(cfg.models.endtime_s / cfg.models.time_per_step)
+    cfg.models.num_subcycles = int(cfg.models.forcing_resolution_h / cfg.models.subcycle_length_h)
+    return cfg
+
+
+def make_model(cfg, soil):
+    from dpLGAR.models.dpLGAR import dpLGAR
+
+    # The reference model indexes an 18-row hard-coded (alpha, n, Ksat) table by soil type
+    # (data/utils.py:108-180); we overwrite the Parameters with the case's values and rebuild.
+    model = dpLGAR(cfg)
+    with torch.no_grad():
+        for i in range(len(soil["alpha"])):
+            model.alpha[i].fill_(soil["alpha"][i])
+            model.n[i].fill_(soil["n"][i])
+            model.ksat[i].fill_(soil["ksat"][i] * cfg.constants.frozen_factor)
+    model.set_internal_states()
+    return model
+
+
+def _f(t):
+    return float(t.detach()) if torch.is_tensor(t) else float(t)
+
+
+def fronts_table(model):
+    z = np.zeros((FREC, 5))
+    lay = np.full((FREC,), -1, dtype=np.int8)
+    bot = np.zeros((FREC,), dtype=np.int8)
+    k = 0
+    layer = model.top_layer
+    while layer is not None:
+        for wf in layer.wetting_fronts:
+            if k < FREC:
+                z[k] = [_f(wf.depth), _f(wf.theta), _f(wf.psi_cm), _f(wf.k_cm_per_h), _f(wf.dzdt)]
+                lay[k] = wf.layer_num
+                bot[k] = 1 if wf.to_bottom else 0
+            k += 1
+        layer = layer.next_layer
+    return z, lay, bot, k
+
+
+ACC_NAMES = ["precip", "PET", "AET", "infiltration", "runoff", "percolation", "giuh_runoff", "discharge",
+             "ponded_water", "ending_volume"]
+
+
+def run_case(name, forcing, soil, pdm, subcycle_s, forcing_res_s, endtime_h, forcing_scale=1.0, grad=False,
+             record_fronts=True, initial_psi=2000.0):
+    torch.set_default_dtype(torch.float64)
+    torch.manual_seed(0)
+    from dpLGAR.data.Data import Data
+    from dpLGAR.models.physics.MassBalance import MassBalance
+
+    tmpdir = tempfile.mkdtemp(prefix="lgar_golden_")
+    fcsv = _fixed_forcing_csv(os.path.join(REF, "data", forcing), tmpdir)
+    sdat = _write_soil_dat(soil, tmpdir)
+    cfg = build_cfg(fcsv, sdat, soil, pdm, subcycle_s, forcing_res_s, endtime_h, initial_psi)
+    data = Data(cfg)
+    x = data.x * forcing_scale
+    T = x.shape[0]
+    model = make_model(cfg, soil)
+    mb = MassBalance(cfg, model)
+
+    acc = np.zeros((T, len(ACC_NAMES)))
+    nfr = np.zeros((T,), dtype=np.int32)
+    prevp = np.zeros((T,))
+    gq = np.zeros((T, 5))
+    fr = np.zeros((T, FREC, 5)) if record_fronts else None
+    fl = np.full((T, FREC), -1, dtype=np.int8) if record_fronts else None
+    fb = np.zeros((T, FREC), dtype=np.int8) if record_fronts else None
+    z0, l0, b0, n0 = fronts_table(model)
+    init_volume = _f(model.ending_volume)
+    crash_step = -1
+    crash_msg = ""
+    runoffs = []
+    t0 = time.time()
+    ctx = torch.enable_grad() if grad else torch.no_grad()
+    with ctx:
+        for i in range(T):
+            try:
+                runoff, perc = model(x[i])
+            except Exception as e:  # the reference dies when a front reaches the domain bottom
+                crash_step = i
+                crash_msg = "%s: %s" % (type(e).__name__, e)
+                break
+            if grad:
+                runoffs.append(runoff)
+            for j, nm in enumerate(ACC_NAMES):
+                acc[i, j] = _f(getattr(model, nm))
+            prevp[i] = _f(model.previous_precip)
+            gq[i] = model.giuh_runoff_queue.detach().numpy()
+            z, lay, bot, k = fronts_table(model)
+            nfr[i] = k
+            if record_fronts:
+                fr[i], fl[i], fb[i] = z, lay, bot
+            mb.change_mass(model)
+    out = dict(
+        forcing=x.numpy(), acc=acc, acc_names=np.array(ACC_NAMES), nfronts=nfr, prev_precip=prevp, giuh_queue=gq,
+        init_fronts=z0, init_layer=l0, init_bottom=b0, init_nfronts=n0, init_volume=init_volume,
+        crash_step=crash_step, crash_msg=crash_msg,
+        alpha=np.array(soil["alpha"]), n=np.array(soil["n"]), ksat=np.array(soil["ksat"]),
+        theta_e=np.array(soil["theta_e"]), theta_r=np.array(soil["theta_r"]), thickness=np.array(soil["thickness"]),
+        pdm=float(pdm), dt_h=float(cfg.models.subcycle_length_h), num_subcycles=int(cfg.models.num_subcycles),
+        initial_psi=float(initial_psi), wilting_point_psi=float(cfg.data.wilting_point_psi),
+        giuh_ordinates=np.array(cfg.data.giuh_ordinates), nint=int(cfg.constants.nint),
+        frozen_factor=float(cfg.constants.frozen_factor),
+        totals=np.array([_f(getattr(mb, nm)) for nm in ACC_NAMES[:8]]),
+    )
+    if record_fronts:
+        out.update(fronts=fr, front_layer=fl, front_bottom=fb)
+    else:
+        z, lay, bot, k = fronts_table(model)
+        out.update(final_fronts=z, final_layer=lay, final_bottom=bot)
+    if grad and crash_step < 0:
+        y = torch.stack(runoffs)
+        loss = torch.mean(y * y)
+        loss.backward()
+
+        def g(plist):
+            return np.array([float(p.grad) if p.grad is not None else np.nan for p in plist])
+
+        out.update(loss=float(loss), d_alpha=g(model.alpha), d_n=g(model.n), d_ksat=g(model.ksat))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    return "%s: T=%d crash=%d (%s) %.1fs maxF=%d" % (name, T, crash_step, crash_msg, time.time() - t0, nfr.max())
+
+
+def perturbed(base, seed, frac=0.10):
+    rng = np.random.default_rng(seed)
+    out = dict(thickness=list(base["thickness"]))
+    for k in ["alpha", "n", "ksat", "theta_e", "theta_r"]:
+        out[k] = [float(v * (1.0 + frac * (2.0 * rng.random() - 1.0))) for v in base[k]]
+    return out
+
+
+def leaf_kats():
+    """Known-answer vectors for the leaf functions (physics/utils.py, lgar/green_ampt.py, aet.py, giuh.py)."""
+    torch.set_default_dtype(torch.float64)
+    from dpLGAR.models.physics import utils as U
+    from dpLGAR.models.physics.lgar.green_ampt import calc_geff
+    from dpLGAR.models.physics.lgar.aet import calc_aet
+    from dpLGAR.models.physics.lgar.giuh import calc_giuh
+
+    class GP:  # the attributes the leaf functions read (GlobalParams.py:74-76,118-128)
+        pass
+
+    gp = GP()
+    gp.device = "cpu"
+    gp.soil_index = dict(theta_r=0, theta_e=1, theta_wp=2, theta_init=3, m=4, bc_lambda=5, bc_psib_cm=6, h_min_cm=7)
+    gp.use_closed_form_G = False
+    gp.nint = torch.tensor(120)
+    gp.relative_moisture_at_which_PET_equals_AET = torch.tensor(0.75)
+    gp.wilting_point_psi_cm = torch.tensor(15495.0)
+    gp.giuh_ordinates = torch.tensor([0.06, 0.51, 0.28, 0.12, 0.03])
+
+    soils = []
+    for s in (PHIL, BUSH, GENERIC):
+        for i in range(3):
+            soils.append((s["alpha"][i], s["n"][i], s["ksat"][i], s["theta_e"][i], s["theta_r"][i]))
+    soils = np.array(soils)
+    hs = np.array([0.0, 0.05, 0.0999, 0.1, 0.5, 1.0, 3.7, 10.0, 55.5, 100.0, 333.0, 1000.0, 2000.0, 15495.0, 1e5])
+    ses = np.array([1e-6, 1e-4, 0.01, 0.1, 0.25, 0.5, 0.75, 0.9, 0.99, 0.999999, 1.0 - 1e-9, 1.0 - 1e-12, 1.0])
+    S, H, E = len(soils), len(hs), len(ses)
+    theta_from_h = np.zeros((S, H)); se_from_h = np.zeros((S, H))
+    k_from_se = np.zeros((S, E)); h_from_se = np.zeros((S, E)); se_from_theta = np.zeros((S, E))
+    fr = np.array([0.02, 0.1, 0.3, 0.5, 0.7, 0.9, 0.98, 1.0])  # theta fractions of (theta_e-theta_r)
+    pairs = [(a, b) for a in range(len(fr)) for b in range(len(fr)) if b > a]
+    geff = np.zeros((S, len(pairs))); geff_t1 = np.zeros((S, len(pairs))); geff_t2 = np.zeros((S, len(pairs)))
+    psis = np.array([0.5, 10.0, 100.0, 500.0, 2000.0, 8000.0, 15495.0])
+    pets = np.array([0.001, 0.02, 0.08])
+    dts = np.array([1.0, 300.0 / 3600.0])
+    aet = np.zeros((S, len(psis), len(pets), len(dts)))
+    T = lambda v: torch.tensor(float(v))
+    for si, (al, n, ks, te, tr) in enumerate(soils):
+        al, n, ks, te, tr = T(al), T(n), T(ks), T(te), T(tr)
+        m = U.calc_m(n)
+        attrs = torch.stack([tr, te, T(0), T(0), m, T(0), T(0), T(0)])
+        for hi, h in enumerate(hs):
+            theta_from_h[si, hi] = float(U.calc_theta_from_h(T(h), al, m, n, te, tr))
+            se_from_h[si, hi] = float(U.calc_se_from_h(T(h), al, m, n))
+        for ei, se in enumerate(ses):
+            k_from_se[si, ei] = float(U.calc_k_from_se(T(se), ks, m))
+            h_from_se[si, ei] = float(U.calc_h_from_se(T(se), al, m, n))
+            se_from_theta[si, ei] = float(U.calc_se_from_theta(tr + T(se) * (te - tr), te, tr))
+        for pi, (a, b) in enumerate(pairs):
+            t1 = tr + T(fr[a]) * (te - tr)
+            t2 = tr + T(fr[b]) * (te - tr)
+            geff_t1[si, pi], geff_t2[si, pi] = float(t1), float(t2)
+            geff[si, pi] = float(calc_geff(gp, attrs, t1, t2, al, n, ks))
+        for pi, psi in enumerate(psis):
+            for qi, pet in enumerate(pets):
+                for di, dt in enumerate(dts):
+                    aet[si, pi, qi, di] = float(calc_aet(gp, float(dt), T(pet), T(psi), te, tr, m, al, n))
+    # giuh: feed a runoff sequence
+    q = torch.zeros(5)
+    ro = [0.0, 0.3, 0.0, 1.2, 0.05, 0.0, 0.0, 0.0, 0.0, 0.0]
+    giuh_out = []; giuh_q = []
+    for r in ro:
+        now, q = calc_giuh(gp, q, T(r))
+        giuh_out.append(float(now)); giuh_q.append(q.numpy().copy())
+    np.savez_compressed(
+        os.path.join(HERE, "leaf_kats.npz"), soils=soils, hs=hs, ses=ses, theta_from_h=theta_from_h,
+        se_from_h=se_from_h, k_from_se=k_from_se, h_from_se=h_from_se, se_from_theta=se_from_theta,
+        geff=geff, geff_theta1=geff_t1, geff_theta2=geff_t2, aet=aet, aet_psis=psis, aet_pets=pets, aet_dts=dts,
+        giuh_runoff_in=np.array(ro), giuh_out=np.array(giuh_out), giuh_queue=np.array(giuh_q),
+    )
+    return "leaf_kats: %d soils" % S
+
+
+PH = "forcing_data_resampled_uniform_Phillipsburg.csv"
+BU = "forcing_data_resampled_uniform_Bushland.csv"
+CASES = {
+    "leaf_kats": (leaf_kats, {}),
+    "phil_hourly_3000": (run_case, dict(forcing=PH, soil=PHIL, pdm=2, subcycle_s=3600, forcing_res_s=3600, endtime_h=3000.0)),
+    "phil_5min_600h": (run_case, dict(forcing=PH, soil=PHIL, pdm=2, subcycle_s=300, forcing_res_s=3600, endtime_h=600.0)),
+    "synth1_phil": (run_case, dict(forcing="forcing_data_synth_1.txt", soil=PHIL, pdm=0.0, subcycle_s=300, forcing_res_s=300, endtime_h=12.0)),
+    "synth2_phil": (run_case, dict(forcing="forcing_data_synth_2.txt", soil=PHIL, pdm=0.0, subcycle_s=300, forcing_res_s=300, endtime_h=12.0)),
+    "synth3_generic": (run_case, dict(forcing="forcing_data_synth_3.txt", soil=GENERIC, pdm=0.5, subcycle_s=300, forcing_res_s=300, endtime_h=12.0)),
+    "synth0_phil_1500": (run_case, dict(forcing="forcing_data_synth_0.csv", soil=PHIL, pdm=0.0, subcycle_s=3600, forcing_res_s=3600, endtime_h=1500.0)),
+    "bushland_hourly_1500": (run_case, dict(forcing=BU, soil=BUSH, pdm=2, subcycle_s=3600, forcing_res_s=3600, endtime_h=1500.0)),
+    "generic_phil_forcing_1000": (run_case, dict(forcing=PH, soil=GENERIC, pdm=1.0, subcycle_s=3600, forcing_res_s=3600, endtime_h=1000.0)),
+    "grad_synth0_12h": (run_case, dict(forcing="forcing_data_synth_0.csv", soil=PHIL, pdm=0.0, subcycle_s=3600, forcing_res_s=3600, endtime_h=12.0, grad=True)),
+    "grad_synth1_phil": (run_case, dict(forcing="forcing_data_synth_1.txt", soil=PHIL, pdm=0.0, subcycle_s=300, forcing_res_s=300, endtime_h=12.0, grad=True)),
+}
+# perturbed-parameter ensembles: the roofline/ensemble configs use ±10 % columns
+for s in range(8):
+    rng = np.random.default_rng(1000 + s)
+    CASES["synth1_pert%d" % s] = (run_case, dict(
+        forcing="forcing_data_synth_1.txt", soil=perturbed(PHIL, s), pdm=0.0, subcycle_s=300, forcing_res_s=300,
+        endtime_h=12.0, forcing_scale=float(0.5 + rng.random())))
+for s in range(4):
+    CASES["phil_pert%d_500" % s] = (run_case, dict(
+        forcing=PH, soil=perturbed(PHIL, 100 + s), pdm=2, subcycle_s=3600, forcing_res_s=3600, endtime_h=500.0))
+
+
+def _run(name):
+    fn, kw = CASES[name]
+    try:
+        return fn(name, **kw) if fn is run_case else fn()
+    except Exception:
+        return "%s FAILED:\n%s" % (name, traceback.format_exc())
+
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or list(CASES)
+    if len(names) == 1:
+        print(_run(names[0]))
+    else:
+        import multiprocessing as mp
+
+        torch.set_num_threads(1)
+        # longest first
+        order = sorted(names, key=lambda n: -CASES[n][1].get("endtime_h", 0) * (3600 / CASES[n][1].get("subcycle_s", 3600)))
+        with mp.get_context("fork").Pool(7) as pool:
+            for msg in pool.imap_unordered(_run, order):
+                print(msg, flush=True)
