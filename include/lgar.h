@@ -1,0 +1,144 @@
+/*
+ * lgar.h -- C-ABI of the MI355X-native many-column LGAR engine (liblgar_hip.so).
+ *
+ * The reference (LGAR-py, "dpLGAR") has no FFI: its only seam is the Python object surface of
+ * dpLGAR(nn.Module) (dpLGAR/models/dpLGAR.py:30-299) as driven by the agent
+ * (dpLGAR/agents/DifferentiableLGAR.py:94-172) and drained by MassBalance
+ * (dpLGAR/models/physics/MassBalance.py:31-53).  The entry points below are what a binding for that
+ * path needs; each cites the reference interface it replaces.  INTEGRATION.md shows the ctypes stub.
+ *
+ * Conventions
+ *  - Plain pointers + sizes; no torch types.  Every pointer is DEVICE memory owned by the caller
+ *    (the library never allocates, frees or copies host<->device), valid on the given stream.
+ *  - All arrays are struct-of-arrays, COLUMN-FASTEST: a per-layer quantity is [n_layers][n_columns],
+ *    a per-front quantity [LGAR_FMAX][n_columns], a forcing / per-step series [n_steps][n_columns].
+ *  - dtype: LGAR_F32 or LGAR_F64 selects the element type of every `void*` array (float / double).
+ *  - Return value: 0 ok; <0 argument / launch error (LGAR_E_*).  Physics faults never abort the
+ *    launch: they set bits in status[column] (the reference raises Python exceptions instead:
+ *    physics/utils.py:17-27,181-183; layers/Layer.py:1206-1208,1115,980).
+ *  - Re-entrant, no globals; one in-flight call per state buffer.  `stream` is a hipStream_t (NULL =
+ *    default stream).
+ */
+#ifndef LGAR_H
+#define LGAR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LGAR_FMAX 16  /* front slots per column (reference lists are unbounded; overflow -> status bit) */
+#define LGAR_LMAX 3   /* soil layers compiled in (BASELINE configs: 3) */
+#define LGAR_GMAX 8   /* GIUH ordinates */
+#define LGAR_NSCAL (3 + LGAR_GMAX) /* scalars row count: ponded_water, previous_precip, ending_volume, giuh_queue[GMAX] */
+#define LGAR_NACC 10  /* precip, PET, AET, infiltration, runoff, percolation, giuh_runoff, discharge, ponded_water, ending_volume */
+
+#define LGAR_F32 0
+#define LGAR_F64 1
+
+#define LGAR_E_ARG (-1)     /* bad argument (null pointer, size out of range, unsupported n_layers) */
+#define LGAR_E_LAUNCH (-2)  /* HIP launch error */
+#define LGAR_E_NODEVICE (-3)
+
+/* status bits, one int32 per column */
+#define LGAR_ST_NAN 1
+#define LGAR_ST_NEGBASE 2
+#define LGAR_ST_THETA_ORDER 4
+#define LGAR_ST_OVERFLOW 8
+#define LGAR_ST_ITERCAP 16
+#define LGAR_ST_BOTTOM 32
+#define LGAR_ST_STRUCT 64
+
+/* front flag byte: low 7 bits layer number, bit 7 = to_bottom (layers/WettingFront.py:39,49) */
+#define LGAR_FLAG_BOTTOM 0x80
+
+/* Run-time constants: the cfg keys dpLGAR(cfg) reads (models/dpLGAR.py:31-95, physics/GlobalParams.py:79-138). */
+typedef struct {
+  int32_t n_columns;      /* N */
+  int32_t n_layers;       /* len(cfg.data.layer_thickness); must be LGAR_LMAX */
+  int32_t n_steps;        /* T forcing rows processed by this call */
+  int32_t num_subcycles;  /* cfg.models.num_subcycles */
+  int32_t nint;           /* cfg.constants.nint (120) */
+  int32_t n_giuh;         /* len(cfg.data.giuh_ordinates) <= LGAR_GMAX */
+  int32_t search_mode;    /* 0 = the reference's literal line searches (Layer.py:275-317, 681-701) */
+  int32_t reserved;
+  double dt_h;               /* cfg.models.subcycle_length_h */
+  double initial_psi;        /* cfg.data.initial_psi */
+  double ponded_depth_max;   /* cfg.data.ponded_depth_max */
+  double wilting_point_psi;  /* cfg.data.wilting_point_psi */
+  double frozen_factor;      /* cfg.constants.frozen_factor */
+  double giuh[LGAR_GMAX];    /* cfg.data.giuh_ordinates */
+  int64_t iter_cap;          /* cap on the reference's unbounded line searches (0 = default) */
+} LgarDims;
+
+/* Per-column soil parameters, each [n_layers][n_columns].  Replaces dpLGAR.alpha/.n/.ksat
+ * (models/dpLGAR.py:50-57), theta_e/theta_r from the soil table (data/utils.py:66-67) and
+ * cfg.data.layer_thickness.  ksat is the value BEFORE frozen_factor is applied. */
+typedef struct {
+  const void *alpha, *n, *ksat, *theta_e, *theta_r, *thickness;
+} LgarParams;
+
+/* Per-column model state (caller-owned, updated in place).  Replaces the Layer/WettingFront object
+ * graph (layers/Layer.py:62-90, layers/WettingFront.py:38-49) and the model attributes
+ * ponded_water / previous_precip / ending_volume / giuh_runoff_queue (models/dpLGAR.py:128-147). */
+typedef struct {
+  void *depth, *theta, *psi, *k, *dzdt; /* each [LGAR_FMAX][n_columns], fronts ordered top -> bottom */
+  uint8_t *flags;                        /* [LGAR_FMAX][n_columns] */
+  int32_t *n_fronts;                     /* [n_columns] */
+  void *scalars;                         /* [LGAR_NSCAL][n_columns] */
+  void *totals;                          /* [LGAR_NACC][n_columns]: run totals, what MassBalance accumulates
+                                            (physics/MassBalance.py:31-44); rows 8,9 hold the latest value */
+} LgarState;
+
+/* Forcing, each [n_steps][n_columns], cm/h (data/Data.py:32-37). */
+typedef struct {
+  const void *precip, *pet;
+} LgarForcing;
+
+/* Optional per-step series, each [n_steps][n_columns] or NULL: the model accumulators as they stand
+ * after forward() and before MassBalance.change_mass zeroes them (order = LGAR_NACC list).
+ * series[4] (runoff) and series[5] (percolation) are forward()'s return pair (models/dpLGAR.py:299). */
+typedef struct {
+  void *series[LGAR_NACC];
+} LgarStepOut;
+
+const char *lgar_version(void);
+int32_t lgar_fmax(void);
+int32_t lgar_lmax(void);
+
+/* dpLGAR.set_internal_states() (models/dpLGAR.py:97-147): one to_bottom front per layer at
+ * psi = initial_psi, theta = theta(initial_psi); zero scalars/totals; status = 0. */
+int32_t lgar_state_init(const LgarDims *dims, const LgarParams *params, LgarState *state, int32_t *status,
+                        int32_t dtype, void *stream);
+
+/* n_steps x dpLGAR.forward(x) (models/dpLGAR.py:154-299) for every column, each followed by the
+ * MassBalance.change_mass drain (physics/MassBalance.py:31-53), i.e. the agent's inner loop
+ * (agents/DifferentiableLGAR.py:117-125).  `out` may be NULL. */
+int32_t lgar_forward(const LgarDims *dims, const LgarParams *params, LgarState *state, const LgarForcing *forcing,
+                     const LgarStepOut *out, int32_t *status, int32_t dtype, void *stream);
+
+/* Forward-mode tangent of lgar_forward (the differentiable path; replaces torch autograd through
+ * forward(), agents/DifferentiableLGAR.py:119,163).  For a parameter direction (d_alpha, d_n, d_ksat,
+ * each [n_layers][n_columns], NULL = 0) it integrates value and tangent together from a FRESH state
+ * (set_internal_states) over n_steps and accumulates, per column,
+ *     grad_out[column] = sum_t  w_runoff[t][column] * d runoff_t + w_perc[t][column] * d percolation_t
+ * (w_* may be NULL).  Line-search offsets are constants w.r.t. the parameters, as in the reference
+ * (Layer.py:277-288,683-696).  tangent_runoff ([n_steps][n_columns]) may be NULL. */
+int32_t lgar_forward_tangent(const LgarDims *dims, const LgarParams *params, const LgarParams *direction,
+                             const LgarForcing *forcing, const void *w_runoff, const void *w_perc,
+                             void *grad_out, void *tangent_runoff, int32_t *status, int32_t dtype, void *stream);
+
+/* Leaf kernels (known-answer tests on the GPU), element-wise over n items:
+ * op 0 theta_from_h(x), 1 se_from_h(x), 2 k_from_se(x), 3 h_from_se(x)      (physics/utils.py:35-174)
+ * op 4 geff(theta1 = x, theta2 = y)                                        (lgar/green_ampt.py:45-84)
+ * op 5 aet(psi = x, pet = y, dt_h = z)                                      (lgar/aet.py:17-51)
+ * alpha, n, ksat, theta_e, theta_r: [n] per-item soil parameters. */
+int32_t lgar_leaf_batch(int32_t op, int32_t n_items, const void *x, const void *y, double z, const void *alpha,
+                        const void *n, const void *ksat, const void *theta_e, const void *theta_r, int32_t nint,
+                        double wilting_point_psi, void *out, int32_t dtype, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,38 @@
+"""Build the HIP library (liblgar_hip.so) in-tree for gfx950 with hipcc."""
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB = os.path.join(CSRC, "liblgar_hip.so")
+SOURCES = ["lgar_kernels.hip", "lgar_tangent.hip"]
+HEADERS = ["lgar_device.hpp", "lgar_dual.hpp", os.path.join("..", "..", "include", "lgar.h")]
+# -ffp-contract=off: expression rounding follows the reference's Python (no FMA contraction)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    for f in SOURCES + HEADERS:
+        fp = os.path.join(CSRC, f)
+        if os.path.exists(fp) and os.path.getmtime(fp) > t:
+            return True
+    return False
+
+
+def build(force=False, verbose=False):
+    """Compile csrc/*.hip -> csrc/liblgar_hip.so.  hipcc cross-compiles gfx950 without a GPU."""
+    if not force and not _stale():
+        return LIB
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found: cannot build liblgar_hip.so")
+    srcs = [os.path.join(CSRC, f) for f in SOURCES if os.path.exists(os.path.join(CSRC, f))]
+    cmd = [hipcc] + FLAGS + srcs + ["-o", LIB]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB

@@ -1,0 +1,810 @@
+// lgar_device.hpp -- device-side LGAR column physics for gfx950 (CDNA4), lane-per-column.
+//
+// One wavefront = 64 independent soil columns.  Per-front state of the wave lives in LDS as
+// [field][front][lane] (lane-contiguous => bank-conflict-free for any per-lane front index), the
+// per-layer van Genuchten parameters and the column scalars live in registers, and the time loop
+// runs inside the kernel.  The scalar type S is float, double, or a forward-mode dual number
+// (lgar_dual.hpp) for the differentiable path.
+//
+// What each routine computes follows the reference's Python (paths relative to
+// /root/reference/dpLGAR/); the data layout and control structure do not: the reference keeps a
+// linked list of Layer objects each owning a Python list of WettingFront objects, here a column is
+// ONE flat top->bottom front array tagged with layer numbers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/lgar.h"
+
+namespace lgar {
+
+constexpr int WAVE = 64;
+
+// ---------------------------------------------------------------------------------------------
+// scalar-type plumbing
+// ---------------------------------------------------------------------------------------------
+template <typename S> struct Real { using type = S; };
+template <typename S> using real_t = typename Real<S>::type;
+
+__device__ __forceinline__ double val(double x) { return x; }
+__device__ __forceinline__ float val(float x) { return x; }
+__device__ __forceinline__ double pw(double x, double y) { return pow(x, y); }
+// fp32: v_log_f32 / v_exp_f32 (quarter-rate transcendentals), ~2-3 ulp for the exponents used here
+__device__ __forceinline__ float pw(float x, float y) { return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)); }
+__device__ __forceinline__ double sq(double x) { return sqrt(x); }
+__device__ __forceinline__ float sq(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ double ab(double x) { return fabs(x); }
+__device__ __forceinline__ float ab(float x) { return fabsf(x); }
+__device__ __forceinline__ double mn(double a, double b) { return fmin(a, b); }
+__device__ __forceinline__ float mn(float a, float b) { return fminf(a, b); }
+__device__ __forceinline__ bool is_nan(double x) { return x != x; }
+__device__ __forceinline__ bool is_nan(float x) { return x != x; }
+
+// tolerances: the reference's absolute 1e-12 (layers/Layer.py:60) is unreachable in fp32
+template <typename R> struct Tol;
+template <> struct Tol<double> {
+  static constexpr double mass = 1e-12;      // Layer.tolerance
+  static constexpr double nochange = 1e-15;  // Layer.py:307,309
+  static constexpr double tiny = 1e-50;      // Layer.py:315
+};
+template <> struct Tol<float> {
+  static constexpr float mass = 2e-5f;
+  static constexpr float nochange = 1e-9f;
+  static constexpr float tiny = 1e-30f;
+};
+
+template <typename S> struct LayerK {
+  S alpha, n, m, inv_m, ninv_m, inv_n, ksat, te, tr;
+};
+
+template <typename S, int NL> struct ColParams {
+  S alpha[NL], n[NL], m[NL], inv_m[NL], ninv_m[NL], inv_n[NL], ksat[NL], te[NL], tr[NL], thick[NL], cum[NL];
+};
+
+template <typename S, int NL> __device__ __forceinline__ S sel(const S (&a)[NL], int k) {
+  // load every element unconditionally, then select on VALUES: a lazily evaluated a[j] becomes a
+  // select of addresses + one load, which pins the whole parameter block in scratch memory
+  S v[NL];
+#pragma unroll
+  for (int j = 0; j < NL; j++) v[j] = a[j];
+  S r = v[0];
+#pragma unroll
+  for (int j = 1; j < NL; j++) r = (k == j) ? v[j] : r;
+  return r;
+}
+
+template <typename S, int NL> __device__ __forceinline__ LayerK<S> pick(const ColParams<S, NL> &P, int k) {
+  LayerK<S> l;
+  l.alpha = sel<S, NL>(P.alpha, k);
+  l.n = sel<S, NL>(P.n, k);
+  l.m = sel<S, NL>(P.m, k);
+  l.inv_m = sel<S, NL>(P.inv_m, k);
+  l.ninv_m = sel<S, NL>(P.ninv_m, k);
+  l.inv_n = sel<S, NL>(P.inv_n, k);
+  l.ksat = sel<S, NL>(P.ksat, k);
+  l.te = sel<S, NL>(P.te, k);
+  l.tr = sel<S, NL>(P.tr, k);
+  return l;
+}
+template <typename S, int NL> __device__ __forceinline__ LayerK<S> pick_static(const ColParams<S, NL> &P, int j) {
+  LayerK<S> l;
+  l.alpha = P.alpha[j]; l.n = P.n[j]; l.m = P.m[j]; l.inv_m = P.inv_m[j]; l.ninv_m = P.ninv_m[j];
+  l.inv_n = P.inv_n[j]; l.ksat = P.ksat[j]; l.te = P.te[j]; l.tr = P.tr[j];
+  return l;
+}
+
+// ---------------------------------------------------------------------------------------------
+// van Genuchten leaf functions (models/physics/utils.py)
+// ---------------------------------------------------------------------------------------------
+// calc_theta_from_h, utils.py:35-51
+template <typename S> __device__ __forceinline__ S theta_from_h(const LayerK<S> &l, S h) {
+  using R = real_t<S>;
+  S ap = pw(l.alpha * h, l.n);
+  S op = pw(R(1.0) + ap, l.m);
+  return (R(1.0) / op * (l.te - l.tr)) + l.tr;
+}
+// calc_se_from_theta, utils.py:102-112
+template <typename S> __device__ __forceinline__ S se_from_theta(const LayerK<S> &l, S theta) {
+  return (theta - l.tr) / (l.te - l.tr);
+}
+// calc_se_from_h, utils.py:115-131 (exactly 1 for |h| < 0.1)
+template <typename S> __device__ __forceinline__ S se_from_h(const LayerK<S> &l, S h) {
+  using R = real_t<S>;
+  if (ab(val(h)) < R(1.0e-01)) return S(R(1.0));
+  S is = pw(l.alpha * h, l.n);
+  return R(1.0) / pw(R(1.0) + is, l.m);
+}
+// calc_k_from_se, utils.py:134-156; torch.isclose(base, 0, rtol=1e-12) => |base| <= 1e-8 (default atol)
+template <typename S> __device__ __forceinline__ S k_from_se(const LayerK<S> &l, S se) {
+  using R = real_t<S>;
+  S sp = pw(se, l.inv_m);
+  S base = R(1.0) - sp;
+  if (ab(val(base)) <= R(1e-8)) base = base + R(1e-12);
+  S op = pw(base, l.m);
+  S t = R(1.0) - op;
+  return l.ksat * sq(se) * (t * t);
+}
+// calc_h_from_se, utils.py:159-174
+template <typename S> __device__ __forceinline__ S h_from_se(const LayerK<S> &l, S se) {
+  using R = real_t<S>;
+  S sp = pw(se, l.ninv_m);
+  S base = sp - R(1.0);
+  if (ab(val(base)) <= R(1e-8)) base = base + R(1e-12);
+  S op = pw(base, l.inv_n);
+  return R(1.0) / l.alpha * op;
+}
+// calc_geff, models/physics/lgar/green_ampt.py:45-84: nint-interval trapezoid of K(h) dh / Ksat.
+// The discretisation error is part of the answer: same nodes (h accumulated by repeated += dh).
+template <typename S> __device__ __forceinline__ S geff(const LayerK<S> &l, S theta1, S theta2, int nint) {
+  using R = real_t<S>;
+  S se_i = se_from_theta(l, theta1);
+  S se_f = se_from_theta(l, theta2);
+  S h_i = h_from_se(l, se_i);
+  S h_f = h_from_se(l, se_f);
+  S dh = (h_f - h_i) / R(nint);
+  S g = S(R(0.0));
+  S k1 = k_from_se(l, se_i);
+  S h2 = h_i + dh;
+  S hdh = dh / R(2.0);
+  for (int i = 0; i < nint; i++) {
+    S se2 = se_from_h(l, h2);
+    S k2 = k_from_se(l, se2);
+    g = g + ((k1 + k2) * hdh);
+    k1 = k2;
+    h2 = h2 + dh;
+  }
+  return ab(g / l.ksat);
+}
+// calc_aet, models/physics/lgar/aet.py:17-51 (0.75: GlobalParams.py:75; clamp upper bound = PET rate)
+template <typename S> __device__ __forceinline__ S aet_fn(const LayerK<S> &l, S pet, real_t<S> dt_h, S psi, real_t<S> wp_psi) {
+  using R = real_t<S>;
+  S theta_fc = (l.te - l.tr) * R(0.75) + l.tr;
+  S wp_head_theta = theta_from_h(l, S(wp_psi));
+  S theta_wp = (theta_fc - wp_head_theta) * R(0.5) + wp_head_theta;
+  S se = se_from_theta(l, theta_wp);
+  S psi_wp = h_from_se(l, se);
+  S r = psi / psi_wp;
+  S h_ratio = R(1.0) + r * r * r;
+  S a = pet * (R(1.0) / h_ratio) * dt_h;
+  if (val(a) < R(0.0)) a = S(R(0.0));
+  if (val(a) > val(pet)) a = pet;
+  return a;
+}
+
+// ---------------------------------------------------------------------------------------------
+// run-time constants shared by all columns (kernel argument -> SGPRs)
+// ---------------------------------------------------------------------------------------------
+template <typename R> struct Glob {
+  R dt_h, initial_psi, pdm, wp_psi, frozen;
+  R giuh[LGAR_GMAX];
+  int nint, nsub, ng, search_mode;
+  long long iter_cap;
+};
+
+// LDS view of one lane's fronts: element i of a field sits at field[i * WAVE]
+template <typename S> struct FrontsView {
+  S *z, *th, *ps, *kk, *dz;
+  unsigned char *fl;
+  __device__ __forceinline__ S &Z(int i) const { return z[i * WAVE]; }
+  __device__ __forceinline__ S &TH(int i) const { return th[i * WAVE]; }
+  __device__ __forceinline__ S &PS(int i) const { return ps[i * WAVE]; }
+  __device__ __forceinline__ S &KK(int i) const { return kk[i * WAVE]; }
+  __device__ __forceinline__ S &DZ(int i) const { return dz[i * WAVE]; }
+  __device__ __forceinline__ int layer(int i) const { return fl[i * WAVE] & 0x7f; }
+  __device__ __forceinline__ bool bottom(int i) const { return (fl[i * WAVE] & LGAR_FLAG_BOTTOM) != 0; }
+  __device__ __forceinline__ void set_flag(int i, int layer, bool bottom) const {
+    fl[i * WAVE] = (unsigned char)(layer | (bottom ? LGAR_FLAG_BOTTOM : 0));
+  }
+  __device__ __forceinline__ void copy(int dst, int src) const {
+    Z(dst) = Z(src); TH(dst) = TH(src); PS(dst) = PS(src); KK(dst) = KK(src); DZ(dst) = DZ(src);
+    fl[dst * WAVE] = fl[src * WAVE];
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// one soil column
+// ---------------------------------------------------------------------------------------------
+template <typename S, int NL, int FMAX> struct Column {
+  using R = real_t<S>;
+  const ColParams<S, NL> &P;
+  const Glob<R> &G;
+  FrontsView<S> F;
+  int nf;
+  int status;
+  S ponded_water, previous_precip, ending_volume;
+  S giuh_q[LGAR_GMAX];
+  // accumulators drained every forcing step (physics/MassBalance.py:45-53)
+  S a_precip, a_pet, a_aet, a_infil, a_runoff, a_perc, a_giuh, a_disch;
+
+  __device__ Column(const ColParams<S, NL> &p, const Glob<R> &g, const FrontsView<S> &f) : P(p), G(g), F(f) {}
+
+  __device__ __forceinline__ S cum_at(int k) const { return sel<S, NL>(P.cum, k); }
+  __device__ __forceinline__ S cum_prev(int k) const {  // cum[k-1], 0 for k == 0
+    S r = S(R(0.0));
+#pragma unroll
+    for (int j = 0; j < NL - 1; j++) {
+      const S cj = P.cum[j];
+      r = (k == j + 1) ? cj : r;
+    }
+    return r;
+  }
+
+  // WettingFront.is_equal (by VALUE), layers/WettingFront.py:76-84
+  __device__ __forceinline__ bool feq(int a, int b) const {
+    return val(F.Z(a)) == val(F.Z(b)) && val(F.PS(a)) == val(F.PS(b)) && val(F.DZ(a)) == val(F.DZ(b));
+  }
+  __device__ __forceinline__ void fdel(int i) {
+    for (int j = i; j < nf - 1; j++) F.copy(j, j + 1);
+    nf--;
+  }
+  // first flat index of layer k and the number of fronts tagged k
+  __device__ __forceinline__ void range_of(int k, int &lo, int &len) const {
+    lo = -1; len = 0;
+    for (int i = 0; i < nf; i++)
+      if (F.layer(i) == k) { if (len == 0) lo = i; len++; }
+  }
+
+  // Layer.mass_balance, layers/Layer.py:795-824 (layer sums combined s0 + (s1 + (s2 ...)))
+  __device__ __forceinline__ S mass_balance() const {
+    S ls[NL];
+    int i = 0;
+#pragma unroll
+    for (int j = 0; j < NL; j++) {
+      S base = (j == 0) ? S(R(0.0)) : P.cum[j] - P.thick[j];
+      S sum = S(R(0.0));
+      while (i < nf && F.layer(i) == j) {
+        bool next_same = (i + 1 < nf) && (F.layer(i + 1) == j);
+        S dth = next_same ? (F.TH(i) - F.TH(i + 1)) : F.TH(i);
+        sum = sum + (F.Z(i) - base) * dth;
+        i++;
+      }
+      ls[j] = sum;
+    }
+    S tot = ls[NL - 1];
+#pragma unroll
+    for (int j = NL - 2; j >= 0; j--) tot = ls[j] + tot;
+    return tot;
+  }
+
+  // calc_wetting_front_free_drainage, Layer.py:134-162: argmin psi, ties (and isclose) go deeper
+  __device__ __forceinline__ int free_drainage_front() const {
+    R psi = val(F.PS(0));
+    int idx = 0;
+    for (int i = 0; i < nf; i++) {
+      R pi = val(F.PS(i));
+      if (pi <= psi) { psi = pi; idx = i; }
+      else if (ab(pi - psi) <= R(1e-8) + R(1e-5) * ab(psi)) { psi = pi; idx = i; }
+    }
+    return idx;
+  }
+
+  // theta_mass_balance, Layer.py:242-318 (+ recalculate_mass :211-240).  k = the front's layer;
+  // dth/dthick hold the entries of the layers above (j < k), dth_k/dthick_k the front's own.
+  __device__ __forceinline__ S theta_mass_balance(int k, const LayerK<S> &lk, S psi, S new_mass, S prior_mass, const S (&dth)[NL],
+                                  const S (&dthick)[NL], S dth_k, S dthick_k) {
+    R delta_mass = ab(val(new_mass) - val(prior_mass));
+    bool switched = false;
+    R factor = R(1.0);
+    S theta = S(R(0.0));
+    S psi_prev = psi;  // a tensor in the reference: psi_prev * 0.1 below carries its gradient
+    R delta_mass_prev = delta_mass;
+    int count_no_change = 0;
+    if (delta_mass <= Tol<R>::mass) return theta_from_h(lk, psi);
+    long long it = 0;
+    while (delta_mass > Tol<R>::mass) {
+      if (++it > G.iter_cap) { status |= LGAR_ST_ITERCAP; break; }
+      if (val(new_mass) > val(prior_mass)) {
+        psi = psi + (R(0.1) * factor);
+        switched = false;
+      } else {
+        if (!switched) { switched = true; factor = factor * R(0.1); }
+        psi_prev = psi;
+        psi = psi - (R(0.1) * factor);
+        if (val(psi) < R(0.0) && val(psi_prev) != R(0.0)) psi = psi_prev * R(0.1);
+      }
+      theta = theta_from_h(lk, psi);
+      S mass = S(R(0.0));
+      mass = mass + (dthick_k * (theta - dth_k));
+#pragma unroll
+      for (int j = 0; j < NL - 1; j++)
+        if (j < k) mass = mass + dthick[j] * (theta_from_h(pick_static(P, j), psi) - dth[j]);
+      new_mass = mass;
+      delta_mass = ab(val(new_mass) - val(prior_mass));
+      if (ab(val(psi) - val(psi_prev)) < Tol<R>::nochange && factor < R(1e-13)) break;
+      if (ab(delta_mass - delta_mass_prev) < Tol<R>::nochange) count_no_change++; else count_no_change = 0;
+      if (count_no_change == 5) break;
+      if (val(psi) <= R(0.0) && val(psi_prev) < Tol<R>::tiny) break;
+      delta_mass_prev = delta_mass;
+    }
+    return theta;
+  }
+
+  // check_column_mass, Layer.py:655-701: depth line search of the (saturated) free-drainage front
+  __device__ __forceinline__ void check_column_mass(int fdd, S old_mass, S percolation, S aet) {
+    S theta_e_k1 = sel<S, NL>(P.te, F.layer(fdd));
+    S mass_timestep = (old_mass + percolation) - (aet + R(0.0));
+    if (ab(val(F.TH(fdd)) - val(theta_e_k1)) < Tol<R>::mass) {
+      S current_mass = mass_balance();
+      R err = ab(val(current_mass) - val(mass_timestep));
+      bool switched = false;
+      R factor = R(1.0);
+      S depth_new = F.Z(fdd);
+      long long it = 0;
+      while (ab(err - Tol<R>::mass) > Tol<R>::mass) {
+        if (++it > G.iter_cap) { status |= LGAR_ST_ITERCAP; break; }
+        R before = val(depth_new);
+        if (val(current_mass) < val(mass_timestep)) {
+          depth_new = depth_new + R(0.01) * factor;
+          switched = false;
+        } else {
+          if (!switched) { switched = true; factor = factor * R(0.001); }
+          depth_new = depth_new - (R(0.01) * factor);
+        }
+        if (sizeof(R) == 4 && val(depth_new) == before && factor < R(1e-6)) break;  // fp32: step below resolution
+        F.Z(fdd) = depth_new;
+        current_mass = mass_balance();
+        err = ab(val(current_mass) - val(mass_timestep));
+      }
+    }
+  }
+
+  // Layer.move_wetting_fronts (Layer.py:1254-1307) with its three cases: deepest_layer_front (:389-418),
+  // wetting_front_in_layer (:420-547, compute_wetting_front_mass :561-644) and base_case (:320-387,
+  // populate_delta_thickness :177-209).  The reference snapshots every front first (copy_states); the
+  // sweep runs deepest -> shallowest and front i only needs the pre-sweep values of i and i+1, so the
+  // snapshot is two register triples carried down the sweep instead of a second front table.
+  // in-layer (layer > 0) and base-case fronts both end in the psi line search: one shared call site.
+  __device__ __forceinline__ void move_sweep(S infiltration, S aet, S old_mass, int fdd) {
+    const int nf0 = nf;
+    S on_z = S(R(0.0)), on_th = S(R(0.0)), on_ps = S(R(0.0));  // pre-sweep values of front i+1
+    int last = nf0 - 1;                                          // last front of the current layer's list
+    for (int i = nf0 - 1; i >= 0; i--) {
+      const int k = F.layer(i);
+      if (i < nf0 - 1 && F.layer(i + 1) != k) last = i;
+      const S oc_z = F.Z(i), oc_th = F.TH(i), oc_ps = F.PS(i);  // pre-sweep values of front i
+      const LayerK<S> lk = pick(P, k);
+      bool need_search = false, need_psi = false;
+      S t_psi = S(R(0.0)), t_new = S(R(0.0)), t_prior = S(R(0.0)), t_dth_k = S(R(0.0)), t_dthick_k = S(R(0.0));
+      S dth[NL], dthick[NL];
+#pragma unroll
+      for (int j = 0; j < NL; j++) { dth[j] = S(R(0.0)); dthick[j] = S(R(0.0)); }
+      if (i < nf0 - 1) {
+        if (i == last || feq(i, last)) {
+          // deepest front of a layer: psi continuity with the layer below
+          F.TH(i) = theta_from_h(lk, F.PS(i + 1));
+          F.PS(i) = F.PS(i + 1);
+        } else if (k == 0) {
+          S prior_mass = oc_z * (oc_th - on_th);
+          if (i == fdd || feq(fdd, i)) prior_mass = prior_mass + (infiltration - (R(0.0) + aet));
+          S z = F.Z(i) + (F.DZ(i) * G.dt_h);
+          z = mn(z, P.cum[NL - 1]);
+          F.Z(i) = z;
+          bool zero_dzdt = ab(val(F.DZ(i))) <= R(1e-8);  // torch.isclose(dzdt, 0, rtol=1e-8): atol 1e-8
+          if (!(zero_dzdt && !F.bottom(i))) {            // a just-created front keeps its theta (Layer.py:458-467)
+            S potential = (prior_mass / z) + F.TH(i + 1);
+            F.TH(i) = mn(lk.te, potential);
+          }
+          need_psi = true;
+        } else {
+          S prev_thick = cum_prev(k);
+          S z = F.Z(i) + (F.DZ(i) * G.dt_h);
+          F.Z(i) = z;
+          S psi_old = oc_ps, psi_below_old = on_ps;
+          S psi = F.PS(i), psi_below = F.PS(i + 1);
+          S prior_mass = (oc_z - prev_thick) * (oc_th - on_th);
+          S new_mass = (z - prev_thick) * (F.TH(i) - F.TH(i + 1));
+#pragma unroll
+          for (int j = 0; j < NL - 1; j++) {
+            if (j < k) {
+              const LayerK<S> lj = pick_static(P, j);
+              S theta_old = theta_from_h(lj, psi_old);
+              S theta_below_old = theta_from_h(lj, psi_below_old);
+              S lt = P.cum[j] - R(0.0);  // quirk: cumulative thickness (Layer.py:603-604)
+              prior_mass = prior_mass + (lt * (theta_old - theta_below_old));
+              S theta = theta_from_h(lj, psi);
+              S theta_below = theta_from_h(lj, psi_below);
+              new_mass = new_mass + (lt * (theta - theta_below));
+              dth[j] = theta_below;
+              dthick[j] = lt;
+            }
+          }
+          t_dth_k = F.TH(i + 1);
+          t_dthick_k = z - prev_thick;
+          if (i == fdd || feq(fdd, i)) prior_mass = prior_mass + infiltration - (R(0.0) + aet);
+          t_psi = psi; t_new = new_mass; t_prior = prior_mass;
+          need_search = true;
+        }
+      } else if (nf0 == NL && k == NL - 1) {
+        // base_case: one front per layer, uniform psi
+        S z = F.Z(i) + F.DZ(i) * G.dt_h;
+        F.Z(i) = z;
+        S psi_old = oc_ps;
+        S psi = F.PS(i);
+        S base = P.cum[NL - 2];
+        S prior_mass = (oc_z - base) * (oc_th - R(0.0));
+        S new_mass = (z - base) * (F.TH(i) - R(0.0));
+#pragma unroll
+        for (int j = 0; j < NL - 1; j++) {
+          const LayerK<S> lj = pick_static(P, j);
+          S theta_old = theta_from_h(lj, psi_old);
+          prior_mass = prior_mass + P.thick[j] * (theta_old - R(0.0));
+          S theta = theta_from_h(lj, psi);
+          new_mass = new_mass + P.thick[j] * (theta - R(0.0));
+          dthick[j] = P.thick[j];
+        }
+        if (F.layer(fdd) == NL - 1) prior_mass = prior_mass + infiltration - (R(0.0) + aet);
+        t_dthick_k = z - base;
+        t_psi = psi; t_new = new_mass; t_prior = prior_mass;
+        need_search = true;
+      }
+      if (need_search) {
+        S theta_new = theta_mass_balance(k, lk, t_psi, t_new, t_prior, dth, dthick, t_dth_k, t_dthick_k);
+        F.TH(i) = mn(theta_new, lk.te);
+        need_psi = true;
+      }
+      if (need_psi) F.PS(i) = h_from_se(lk, se_from_theta(lk, F.TH(i)));
+      if (i == 0) check_column_mass(fdd, old_mass, infiltration, aet);
+      on_z = oc_z; on_th = oc_th; on_ps = oc_ps;
+    }
+  }
+
+  // merge_wetting_fronts / is_passing / pass_front / delete_front, Layer.py:826-892: per layer, the first
+  // front that has passed its (same-layer, non-boundary) successor absorbs it; <= 1 merge per layer per call.
+  __device__ __forceinline__ void merge_fronts() {
+    int i = 0, lo = 0;
+    while (i < nf - 1) {
+      const int k = F.layer(i);
+      if (i > 0 && F.layer(i - 1) != k) lo = i;
+      const int nx = i + 1;
+      const bool passing = (val(F.Z(i)) > val(F.Z(nx))) && (F.layer(nx) == k) && !F.bottom(nx);
+      if (!passing) { i++; continue; }
+      const int nn = i + 2;
+      if (nn >= nf) { status |= LGAR_ST_STRUCT; return; }
+      const LayerK<S> lk = pick(P, k);
+      S mass = F.Z(i) * (F.TH(i) - F.TH(nx)) + F.Z(nx) * (F.TH(nx) - F.TH(nn));
+      F.Z(i) = mass / (F.TH(i) - F.TH(nn));
+      S se = se_from_theta(lk, F.TH(i));
+      F.PS(i) = h_from_se(lk, se);
+      F.KK(i) = k_from_se(lk, se);
+      // delete_front: the first front of THIS layer's list that is value-equal to `next`
+      int j = lo;
+      while (j < nf && F.layer(j) == k && !feq(j, nx)) j++;
+      if (j < nf && F.layer(j) == k) fdel(j);
+      // this layer is done: continue with the first front of the next layer
+      i = lo;
+      while (i < nf && F.layer(i) == k) i++;
+      lo = i;
+    }
+  }
+
+  // wetting_fronts_cross_layer_boundary / recalibrate, Layer.py:894-1008: a front that has advanced past its
+  // layer's lower boundary swaps roles with the boundary front.  On the flat array the re-bucketing
+  // (update_wetting_fronts :939-963) is just the tag change; the moved front is not revisited in this call.
+  __device__ __forceinline__ void cross_layer_boundary() {
+    int i = 0;
+    while (i < nf - 1) {
+      const int k = F.layer(i);
+      const int nx = i + 1, nn = i + 2;
+      const S cumk = cum_at(k);
+      if (!(val(F.Z(i)) > val(cumk) && val(F.Z(nx)) == val(cumk))) { i++; continue; }
+      if (k == NL - 1) { status |= LGAR_ST_BOTTOM; return; }  // reference: AttributeError at Layer.py:980
+      if (nn >= nf) { status |= LGAR_ST_STRUCT; return; }
+      const LayerK<S> lk = pick(P, k);
+      const LayerK<S> ln = pick(P, k + 1);
+      S overshot = F.Z(i) - F.Z(nx);
+      S se = se_from_theta(lk, F.TH(i));
+      F.PS(i) = h_from_se(lk, se);
+      F.KK(i) = k_from_se(lk, se);
+      S theta_new = theta_from_h(ln, F.PS(i));
+      S mbal = overshot * (F.TH(i) - F.TH(nx));
+      S zc = mbal / (theta_new - F.TH(nn));
+      S depth_new = cumk + zc;
+      F.Z(i) = cumk;
+      F.TH(nx) = theta_new;
+      F.PS(nx) = F.PS(i);
+      F.Z(nx) = depth_new;
+      F.DZ(nx) = F.DZ(i);
+      F.DZ(i) = S(R(0.0));
+      F.set_flag(i, k, true);
+      F.set_flag(nx, k + 1, false);
+      i += 2;
+    }
+  }
+
+  // fix_dry_over_wet_fronts / cleanup_wetting_fronts / update_layer_fronts, Layer.py:1055-1143: per layer,
+  // the first front that is not wetter than its same-layer successor is deleted (<= 1 per layer per call).
+  __device__ __forceinline__ S fix_dry_over_wet() {
+    S ls[NL];
+#pragma unroll
+    for (int j = 0; j < NL; j++) ls[j] = S(R(0.0));
+    int i = 0;
+    while (i < nf - 1) {
+      const int k = F.layer(i);
+      const int nx = i + 1;
+      if (!(val(F.TH(i)) <= val(F.TH(nx)) && F.layer(nx) == k)) { i++; continue; }
+      S before = mass_balance();
+      fdel(i);  // the next front now sits at index i
+      if (k > 0) {
+        int found = 0;
+        while (found < nf && !feq(found, i)) found++;
+        if (found >= nf) status |= LGAR_ST_STRUCT;
+        else {
+          const int lj = F.layer(found);
+          const LayerK<S> lf = pick(P, lj);
+          F.PS(found) = h_from_se(lf, se_from_theta(lf, F.TH(found)));
+          const S dry_th = F.TH(found), dry_ps = F.PS(found);
+          for (int q = 0; q < nf; q++) {
+            const int lq = F.layer(q);
+            if (lq < lj) {  // quirk: EVERY front of all shallower layers is overwritten (Layer.py:1117-1143)
+              const LayerK<S> lql = pick(P, lq);
+              F.PS(q) = h_from_se(lql, se_from_theta(lql, dry_th));
+              F.TH(q) = theta_from_h(lql, dry_ps);
+            }
+          }
+        }
+      }
+      S after = mass_balance();
+      S mc = ab(after - before);
+#pragma unroll
+      for (int j = 0; j < NL; j++) ls[j] = (k == j) ? (ls[j] + mc) : ls[j];
+      // this layer is done: continue with the first front of the next layer
+      while (i < nf && F.layer(i) == k) i++;
+    }
+    S tot = ls[NL - 1];
+#pragma unroll
+    for (int j = NL - 2; j >= 0; j--) tot = ls[j] + tot;
+    return tot;
+  }
+
+  // update_psi, Layer.py:1157-1174: psi and K from theta for every front but the deepest of the domain
+  __device__ __forceinline__ void update_psi() {
+    for (int i = 0; i < nf - 1; i++) {
+      const LayerK<S> lk = pick(P, F.layer(i));
+      S se = se_from_theta(lk, F.TH(i));
+      F.PS(i) = h_from_se(lk, se);
+      F.KK(i) = k_from_se(lk, se);
+    }
+  }
+
+  // dpLGAR.move_wetting_front, models/dpLGAR.py:340-367.  Returns the bottom-boundary flux.
+  // wetting_front_cross_domain_boundary (Layer.py:1010-1053) cannot be reached in the reference without
+  // crashing in the layer-boundary step first; here that case sets LGAR_ST_BOTTOM and the flux is 0.
+  __device__ __forceinline__ S move_wetting_front(S infiltration, S &aet, S old_mass, int fdd) {
+    move_sweep(infiltration, aet, old_mass, fdd);
+    for (int pass = 0; pass < 2; pass++) {
+      merge_fronts();
+      if (pass == 0) cross_layer_boundary();
+    }
+    S bottom_flux = S(R(0.0));
+    S mass_change = fix_dry_over_wet();
+    if (ab(val(mass_change)) > R(1e-7)) aet = aet - mass_change;
+    update_psi();
+    return bottom_flux;
+  }
+
+  // calc_dzdt, Layer.py:1176-1252 (calc_bottom_sum :1557-1582): one Geff per moving front
+  __device__ __forceinline__ void calc_dzdt(S h_p) {
+    for (int i = 0; i < nf - 1; i++) {
+      if (F.bottom(i)) { F.DZ(i) = S(R(0.0)); continue; }
+      const int k = F.layer(i);
+      const LayerK<S> lk = pick(P, k);
+      S theta_1 = F.TH(i + 1), theta_2 = F.TH(i);
+      if (k == 0 && val(theta_1) > val(theta_2)) status |= LGAR_ST_THETA_ORDER;  // Layer.py:1206-1208
+      S delta_theta = F.TH(i) - F.TH(i + 1);
+      S dzdt = S(R(0.0));
+      if (val(delta_theta) > R(0.0)) {
+        S g = geff(lk, theta_1, theta_2, G.nint);
+        if (k == 0) {
+          dzdt = R(1.0) / delta_theta * (lk.ksat * (g + h_p) / F.Z(i) + F.KK(i));
+        } else {
+          S den = S(R(0.0)) + (F.Z(i) - cum_prev(k)) / F.KK(i);
+#pragma unroll
+          for (int j = 0; j < NL - 1; j++)
+            if (j < k) {
+              const LayerK<S> lj = pick_static(P, j);
+              S tl = theta_from_h(lj, F.PS(i));
+              S kl = k_from_se(lj, se_from_theta(lj, tl));
+              S pt = (j != 0) ? P.cum[(j > 0) ? j - 1 : 0] : S(R(0.0));
+              den = den + ((P.cum[j] - pt) / kl);
+            }
+          dzdt = (R(1.0) / delta_theta) * ((F.Z(i) / den) + lk.ksat * (g + h_p) / F.Z(i));
+        }
+      }
+      F.DZ(i) = dzdt;
+    }
+  }
+
+  // calc_dry_depth, Layer.py:1309-1334
+  __device__ __forceinline__ S calc_dry_depth() {
+    const LayerK<S> l0 = pick_static(P, 0);
+    S delta_theta = l0.te - F.TH(0);
+    S tau = G.dt_h * l0.ksat / delta_theta;
+    S g = geff(l0, F.TH(0), l0.te, G.nint);
+    S dry = R(0.5) * (tau + sq(tau * tau + R(4.0) * tau * g));
+    return mn(P.cum[0], dry);
+  }
+
+  // Layer.create_surficial_front, Layer.py:1336-1416
+  __device__ __forceinline__ void create_surficial_front(S dry_depth, S &ponded, S &infiltration) {
+    if (nf >= FMAX) { status |= LGAR_ST_OVERFLOW; return; }
+    const LayerK<S> l0 = pick_static(P, 0);
+    S cur_theta = F.TH(0);
+    S delta_theta = l0.te - cur_theta;
+    S theta_new;
+    bool to_bottom = false;
+    if (val(dry_depth * delta_theta) > val(ponded)) {
+      infiltration = ponded;
+      theta_new = mn((cur_theta + ponded / dry_depth), l0.te);
+      ponded = S(R(0.0));
+    } else {
+      infiltration = dry_depth * delta_theta;
+      ponded = ponded - (dry_depth * delta_theta);
+      theta_new = l0.te;
+      to_bottom = !(val(dry_depth) < val(P.cum[0]));
+    }
+    for (int j = nf; j > 0; j--) F.copy(j, j - 1);
+    nf++;
+    F.Z(0) = dry_depth;
+    F.TH(0) = theta_new;
+    F.set_flag(0, 0, to_bottom);
+    S se = se_from_theta(l0, theta_new);
+    F.PS(0) = h_from_se(l0, se);
+    F.KK(0) = k_from_se(l0, se) * G.frozen;
+    F.DZ(0) = S(R(0.0));
+  }
+
+  // insert_water, Layer.py:1418-1536 (get_drainage_neighbors :1584-1607, calc_bottom_sum_f_p :1538-1555):
+  // Green-Ampt infiltration capacity f_p and the infiltration / runoff / ponding split
+  __device__ __forceinline__ void insert_water(int fdd, S precip, S &ponded, S &infiltration, S &runoff) {
+    const R dt = G.dt_h;
+    S h_p = (ponded - precip) * dt;
+    if (val(h_p) < R(0.0)) h_p = S(R(0.0));
+    const int kfp = F.layer(fdd);
+    int lo, len;
+    range_of(kfp, lo, len);
+    const int nxt_i = lo + 1;  // the front after the FIRST front of the free-drainage front's layer (quirk)
+    if (nxt_i >= nf) { status |= LGAR_ST_STRUCT; return; }
+    const LayerK<S> lk = pick(P, kfp);
+    S g = S(R(0.0));
+    if (nf != NL) g = geff(lk, F.TH(nxt_i), lk.te, G.nint);
+    S f_p;
+    if (kfp == 0) {
+      f_p = P.ksat[0] * (R(1.0) + (g + h_p) / F.Z(fdd));
+    } else {
+      S fd_ksat = lk.ksat * G.frozen;
+      S bottom_sum = (F.Z(fdd) - cum_prev(kfp)) / fd_ksat;
+      bottom_sum = bottom_sum + ((P.cum[0] - R(0.0)) / (P.ksat[0] * G.frozen));
+#pragma unroll
+      for (int j = 1; j < NL - 1; j++)
+        if (j < kfp) {
+          const LayerK<S> lj = pick_static(P, j);
+          S tl = theta_from_h(lj, F.PS(fdd));
+          S kl = k_from_se(lj, se_from_theta(lj, tl));
+          bottom_sum = bottom_sum + ((P.cum[j] - P.cum[j - 1]) / kl);
+        }
+      f_p = (F.Z(fdd) / bottom_sum) + ((g + h_p) * fd_ksat / F.Z(fdd));
+    }
+    S pond_temp = ponded - f_p * dt;
+    if (val(pond_temp) < R(0.0)) pond_temp = S(R(0.0));
+    S fp_cm = f_p * dt;
+    if (G.pdm > R(0.0)) {
+      if (val(pond_temp) < G.pdm) {
+        infiltration = mn(ponded, fp_cm);
+        ponded = ponded - infiltration;
+      } else if (val(pond_temp) > G.pdm) {
+        ponded = S(G.pdm);
+        infiltration = fp_cm;
+      }
+      S r = pond_temp - G.pdm;
+      runoff = (val(r) > R(0.0)) ? r : S(R(0.0));
+    } else {
+      infiltration = mn(ponded, fp_cm);
+      S r = ponded - infiltration;
+      ponded = S(G.pdm);
+      runoff = (val(r) > R(0.0)) ? r : S(R(0.0));
+    }
+  }
+
+  // dpLGAR.set_internal_states, models/dpLGAR.py:97-147
+  __device__ __forceinline__ void init_state() {
+    nf = NL;
+    status = 0;
+#pragma unroll
+    for (int k = 0; k < NL; k++) {
+      const LayerK<S> lk = pick_static(P, k);
+      F.Z(k) = P.cum[k];
+      F.TH(k) = theta_from_h(lk, S(G.initial_psi));
+      F.PS(k) = S(G.initial_psi);
+      F.KK(k) = k_from_se(lk, se_from_theta(lk, F.TH(k)));
+      F.DZ(k) = S(R(0.0));
+      F.set_flag(k, k, true);
+    }
+    ponded_water = previous_precip = S(R(0.0));
+#pragma unroll
+    for (int i = 0; i < LGAR_GMAX; i++) giuh_q[i] = S(R(0.0));
+    ending_volume = mass_balance();
+    drain();
+  }
+
+  __device__ __forceinline__ void drain() {
+    a_precip = a_pet = a_aet = a_infil = a_runoff = a_perc = a_giuh = a_disch = S(R(0.0));
+  }
+
+  // dpLGAR.forward, models/dpLGAR.py:154-299: one forcing step = nsub sub-steps
+  __device__ __forceinline__ void forward(S precip, S pet) {
+    const R dt = G.dt_h;
+    S ending_volume_sub = ending_volume;
+    for (int sub = 0; sub < G.nsub; sub++) {
+      if (status & (LGAR_ST_BOTTOM | LGAR_ST_OVERFLOW | LGAR_ST_STRUCT)) return;  // dead column
+      S precip_sub = precip * dt;
+      S pet_sub = pet * dt;
+      S ponded_depth_sub = precip_sub + ponded_water;
+      S ponded_water_sub = S(R(0.0)), runoff_sub = S(R(0.0)), infiltration_sub = S(R(0.0)), AET_sub = S(R(0.0));
+      // create_surficial_front predicate, models/dpLGAR.py:310-323
+      const bool create = (val(previous_precip) == R(0.0)) && (val(precip_sub) > R(0.0)) && (val(ponded_water) == R(0.0));
+      const int fdd = free_drainage_front();
+      const bool saturated = val(F.TH(0)) >= val(P.te[0]);  // Layer.is_saturated, Layer.py:785-793
+      if (val(pet) > R(0.0)) AET_sub = aet_fn(pick_static(P, 0), pet, dt, F.PS(0), G.wp_psi);
+      a_precip = a_precip + precip_sub;
+      a_pet = a_pet + ((val(pet_sub) > R(0.0)) ? pet_sub : S(R(0.0)));
+      // Single call site for the front move (models/dpLGAR.py:199-266 re-ordered, same data flow): columns
+      // that create a surficial front move first with zero infiltration and then create it; the others
+      // infiltrate (insert_water) and then move.  update_ponded_depth touches no front state, so doing it
+      // after the move is equivalent.
+      const bool inserting = !create && val(ponded_depth_sub) > R(0.0);
+      if (inserting) {
+        insert_water(fdd, precip_sub, ponded_depth_sub, infiltration_sub, runoff_sub);
+        a_infil = a_infil + infiltration_sub;
+        a_runoff = a_runoff + runoff_sub;
+        ponded_water_sub = ponded_depth_sub;
+      }
+      if (!create || !saturated) {
+        S perc_sub = move_wetting_front(create ? S(R(0.0)) : infiltration_sub, AET_sub, ending_volume_sub, fdd);
+        if (!create) a_perc = a_perc + perc_sub;
+      }
+      if (create && !saturated) {
+        S dry_depth = calc_dry_depth();
+        create_surficial_front(dry_depth, ponded_depth_sub, infiltration_sub);
+        a_infil = a_infil + infiltration_sub;
+      }
+      if (!inserting) {
+        // update_ponded_depth, models/dpLGAR.py:369-382
+        if (val(ponded_depth_sub) < G.pdm) {
+          runoff_sub = S(R(0.0));
+          ponded_water_sub = ponded_depth_sub;
+          ponded_depth_sub = S(R(0.0));
+        } else {
+          runoff_sub = ponded_depth_sub - G.pdm;
+          ponded_depth_sub = S(G.pdm);
+          ponded_water_sub = ponded_depth_sub;
+          a_runoff = a_runoff + runoff_sub;
+        }
+      }
+      calc_dzdt(ponded_depth_sub);
+      ending_volume_sub = mass_balance();
+      previous_precip = precip_sub;
+      ending_volume = ending_volume_sub;
+      a_aet = a_aet + AET_sub;
+      ponded_water = ponded_water_sub;
+      // GIUH, models/dpLGAR.py:292-298 and lgar/giuh.py:8-20
+      R qsum = R(0.0);
+#pragma unroll
+      for (int i = 0; i < LGAR_GMAX; i++) if (i < G.ng) qsum += val(giuh_q[i]);
+      if (qsum > R(0.0) || val(runoff_sub) > R(0.0)) {
+#pragma unroll
+        for (int i = 0; i < LGAR_GMAX; i++) if (i < G.ng) giuh_q[i] = giuh_q[i] + (G.giuh[i] * runoff_sub);
+        S now = giuh_q[0];
+#pragma unroll
+        for (int i = 0; i < LGAR_GMAX - 1; i++) giuh_q[i] = (i < G.ng - 1) ? giuh_q[i + 1] : S(R(0.0));
+        giuh_q[LGAR_GMAX - 1] = S(R(0.0));
+        a_giuh = a_giuh + now;
+        a_disch = a_disch + now;
+      }
+      bool bad = false;
+      for (int i = 0; i < nf; i++) bad = bad || is_nan(val(F.TH(i))) || is_nan(val(F.Z(i))) || is_nan(val(F.PS(i)));
+      if (bad) status |= LGAR_ST_NAN;
+    }
+  }
+};
+
+}  // namespace lgar

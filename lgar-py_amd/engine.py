@@ -1,0 +1,187 @@
+"""Many-column LGAR engine: owns the struct-of-arrays device state and drives the HIP kernels
+through the C-ABI (include/lgar.h).  Host-side mirror of what dpLGAR(nn.Module) keeps per column
+(/root/reference/dpLGAR/models/dpLGAR.py:97-147), laid out column-fastest in HBM.
+
+PyTorch is plumbing here (device memory, streams); the computation is in csrc/*.hip.
+"""
+import ctypes as C
+
+import torch
+
+from . import _capi
+from ._capi import ACC_NAMES, FMAX, GMAX, LMAX, NACC, NSCAL, LgarError
+
+
+def _require_gpu(device):
+    if not torch.cuda.is_available():
+        raise LgarError("no ROCm GPU visible: the LGAR engine has no CPU fallback (device=%s)" % (device,))
+
+
+class LgarStatusError(ValueError):
+    """Physics fault in one or more columns (the reference raises ValueError / IndexError / AttributeError)."""
+
+
+class LgarEngine:
+    """N independent soil columns advanced by the gfx950 kernels.
+
+    Parameters are [L] (shared by all columns) or [L, N] tensors/sequences; forcing is [T, N] (cm/h).
+    """
+
+    def __init__(self, alpha, n, ksat, theta_e, theta_r, thickness, *, n_columns=None, dt_h=1.0, num_subcycles=1,
+                 initial_psi=2000.0, ponded_depth_max=0.0, wilting_point_psi=15495.0, frozen_factor=1.0, nint=120,
+                 giuh_ordinates=(0.06, 0.51, 0.28, 0.12, 0.03), dtype=torch.float64, device="cuda:0",
+                 iter_cap=0, search_mode=0):
+        self.device = torch.device(device)
+        _require_gpu(self.device)
+        self.lib = _capi.load()
+        if dtype not in (torch.float32, torch.float64):
+            raise LgarError("dtype must be torch.float32 or torch.float64")
+        self.dtype = dtype
+        self._dt = _capi.F64 if dtype == torch.float64 else _capi.F32
+
+        def prep(x):
+            t = torch.as_tensor(x, dtype=torch.float64)
+            if t.dim() == 1:
+                if n_columns is None:
+                    raise LgarError("n_columns is required when parameters are per-layer vectors")
+                t = t[:, None].expand(-1, n_columns)
+            return t.to(self.device, dtype).contiguous()
+
+        self.alpha, self.n, self.ksat = prep(alpha), prep(n), prep(ksat)
+        self.theta_e, self.theta_r, self.thickness = prep(theta_e), prep(theta_r), prep(thickness)
+        L, N = self.alpha.shape
+        if L != LMAX:
+            raise LgarError("this build supports exactly %d soil layers (got %d)" % (LMAX, L))
+        for t in (self.n, self.ksat, self.theta_e, self.theta_r, self.thickness):
+            if tuple(t.shape) != (L, N):
+                raise LgarError("parameter shapes differ: expected %s, got %s" % ((L, N), tuple(t.shape)))
+        if len(giuh_ordinates) > GMAX:
+            raise LgarError("at most %d GIUH ordinates" % GMAX)
+        self.L, self.N = L, N
+        self.dims = _capi.LgarDims()
+        d = self.dims
+        d.n_columns, d.n_layers, d.n_steps, d.num_subcycles = N, L, 0, int(num_subcycles)
+        d.nint, d.n_giuh, d.search_mode = int(nint), len(giuh_ordinates), int(search_mode)
+        d.dt_h, d.initial_psi, d.ponded_depth_max = float(dt_h), float(initial_psi), float(ponded_depth_max)
+        d.wilting_point_psi, d.frozen_factor = float(wilting_point_psi), float(frozen_factor)
+        for i, g in enumerate(giuh_ordinates):
+            d.giuh[i] = float(g)
+        d.iter_cap = int(iter_cap)
+
+        z = lambda *shape, dt=dtype: torch.zeros(*shape, dtype=dt, device=self.device)
+        self.depth, self.theta, self.psi = z(FMAX, N), z(FMAX, N), z(FMAX, N)
+        self.k, self.dzdt = z(FMAX, N), z(FMAX, N)
+        self.flags = z(FMAX, N, dt=torch.uint8)
+        self.n_fronts = z(N, dt=torch.int32)
+        self.scalars = z(NSCAL, N)
+        self.totals = z(NACC, N)
+        self.status = z(N, dt=torch.int32)
+
+        self._params = _capi.LgarParams(*[t.data_ptr() for t in (self.alpha, self.n, self.ksat, self.theta_e,
+                                                                 self.theta_r, self.thickness)])
+        self._state = _capi.LgarState(*[t.data_ptr() for t in (self.depth, self.theta, self.psi, self.k, self.dzdt,
+                                                               self.flags, self.n_fronts, self.scalars, self.totals)])
+        self.reset()
+
+    # ------------------------------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def reset(self):
+        """dpLGAR.set_internal_states() for every column."""
+        with torch.cuda.device(self.device):
+            rc = self.lib.lgar_state_init(C.byref(self.dims), C.byref(self._params), C.byref(self._state),
+                                          self.status.data_ptr(), self._dt, self._stream())
+        _capi.check(rc, "lgar_state_init")
+
+    def forward(self, precip, pet, series=("runoff", "percolation"), out=None, check=True):
+        """Advance every column by T forcing steps.  precip/pet: [T, N] cm/h on self.device.
+
+        Returns {name: tensor[T, N]} for the requested per-step series (the model accumulators as they
+        stand after each forward(), before MassBalance.change_mass zeroes them)."""
+        precip = torch.as_tensor(precip).to(self.device, self.dtype).contiguous()
+        pet = torch.as_tensor(pet).to(self.device, self.dtype).contiguous()
+        if precip.dim() == 1:
+            precip, pet = precip[None, :], pet[None, :]
+        if precip.shape != pet.shape or precip.shape[1] != self.N:
+            raise LgarError("forcing must be [T, %d]; got %s / %s" % (self.N, tuple(precip.shape), tuple(pet.shape)))
+        T = precip.shape[0]
+        res = {}
+        so = _capi.LgarStepOut()
+        for nm in series:
+            j = ACC_NAMES.index(nm)
+            buf = out[nm] if out is not None and nm in out else torch.empty(T, self.N, dtype=self.dtype, device=self.device)
+            if tuple(buf.shape) != (T, self.N) or buf.dtype != self.dtype or not buf.is_contiguous():
+                raise LgarError("bad output buffer for series %r" % nm)
+            res[nm] = buf
+            so.series[j] = buf.data_ptr()
+        self.dims.n_steps = T
+        fo = _capi.LgarForcing(precip.data_ptr(), pet.data_ptr())
+        with torch.cuda.device(self.device):
+            rc = self.lib.lgar_forward(C.byref(self.dims), C.byref(self._params), C.byref(self._state), C.byref(fo),
+                                       C.byref(so), self.status.data_ptr(), self._dt, self._stream())
+        _capi.check(rc, "lgar_forward")
+        if check:
+            self.check_status()
+        return res
+
+    def check_status(self):
+        """Raise like the reference does (ValueError) if any column hit a physics fault."""
+        bad = int((self.status != 0).sum().item())
+        if bad:
+            bits = int(torch.bitwise_or(self.status, torch.zeros_like(self.status)).max().item())
+            allbits = 0
+            for b in _capi.STATUS_NAMES:
+                if int(((self.status & b) != 0).sum().item()):
+                    allbits |= b
+            names = [v for b, v in _capi.STATUS_NAMES.items() if allbits & b]
+            first = int(torch.nonzero(self.status)[0].item())
+            raise LgarStatusError("%d of %d columns faulted (%s); first column %d, max status %d"
+                                  % (bad, self.N, ", ".join(names), first, bits))
+
+    # ------------------------------------------------------------------------------------------
+    def fronts(self):
+        """Front tables as host numpy arrays: depth/theta/psi/k/dzdt [FMAX, N], layer, to_bottom, n_fronts."""
+        fl = self.flags.cpu().numpy()
+        return dict(depth=self.depth.cpu().numpy(), theta=self.theta.cpu().numpy(), psi=self.psi.cpu().numpy(),
+                    k=self.k.cpu().numpy(), dzdt=self.dzdt.cpu().numpy(), layer=(fl & 0x7F).astype("int8"),
+                    to_bottom=(fl >> 7).astype("int8"), n_fronts=self.n_fronts.cpu().numpy())
+
+    def total(self, name):
+        return self.totals[ACC_NAMES.index(name)]
+
+    @property
+    def ponded_water(self):
+        return self.scalars[0]
+
+    @property
+    def previous_precip(self):
+        return self.scalars[1]
+
+    @property
+    def ending_volume(self):
+        return self.scalars[2]
+
+    @property
+    def giuh_runoff_queue(self):
+        return self.scalars[3:3 + self.dims.n_giuh]
+
+
+def leaf_batch(op, x, y=None, z=0.0, *, alpha, n, ksat, theta_e, theta_r, nint=120, wilting_point_psi=15495.0,
+               dtype=torch.float64, device="cuda:0"):
+    """Element-wise leaf kernels (known-answer tests): see lgar_leaf_batch in include/lgar.h."""
+    dev = torch.device(device)
+    _require_gpu(dev)
+    lib = _capi.load()
+    ops = {"theta_from_h": 0, "se_from_h": 1, "k_from_se": 2, "h_from_se": 3, "geff": 4, "aet": 5}
+    prep = lambda t: None if t is None else torch.as_tensor(t, dtype=torch.float64).to(dev, dtype).contiguous()
+    x, y, alpha, n, ksat, theta_e, theta_r = map(prep, (x, y, alpha, n, ksat, theta_e, theta_r))
+    out = torch.empty_like(x)
+    ptr = lambda t: None if t is None else t.data_ptr()
+    with torch.cuda.device(dev):
+        rc = lib.lgar_leaf_batch(ops[op], x.numel(), ptr(x), ptr(y), float(z), ptr(alpha), ptr(n), ptr(ksat),
+                                 ptr(theta_e), ptr(theta_r), int(nint), float(wilting_point_psi), ptr(out),
+                                 _capi.F64 if dtype == torch.float64 else _capi.F32,
+                                 C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    _capi.check(rc, "lgar_leaf_batch")
+    return out
