@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py -- column-timesteps/s of the LGAR hot path on MI355X (BASELINE.json metric).
+
+Workload (BASELINE.json configs[2]/[3]): per GPU, 1M synthetic columns
+(Phillipsburg P-1..3 soils perturbed +-10 % per column, forcing_data_synth_1 shape x per-column
+scale U(0.5,1.5)), 3 layers, fp32, T = 144 five-minute steps per pass.  One "step" = one pass of
+the hot path over that batch: set_internal_states + 144 x forward() for every column (one kernel
+launch with the time loop inside) + the basin-runoff reduction [T] (RCCL all-reduce when N > 1).
+Inputs are resident in HBM before the timed region.  Weak scaling: columns per GPU fixed.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def alg_bytes_per_col_step(elem, T, L=3, fmax=16):
+    """B_alg = 4*s + B_col/T; B_col = L*6*s + 2*F_MAX*(5*s+1) + 2*16*s."""
+    b_col = L * 6 * elem + 2 * fmax * (5 * elem + 1) + 2 * 16 * elem
+    return 4 * elem + b_col / T
+
+
+def cpu_baseline(target_s=12.0):
+    """Oracle (C restatement, fp64, OpenMP over columns) timed on this host on a bounded sample of the
+    same workload.  A reported baseline, never the thing measured above."""
+    from lgar_py_amd import workloads as W
+    from oracle import lgar_oracle as O
+
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    f = W.synth1_forcing()
+    T = f.shape[0]
+
+    def run(n):
+        P = W.perturbed_columns(n, seed=0)
+        sc = W.forcing_scale(n, seed=1)
+        pr = f[:, 0:1] * sc[None, :]
+        pe = np.zeros_like(pr)
+        t0 = time.perf_counter()
+        O.run_columns(P["alpha"], P["n"], P["ksat"], P["theta_e"], P["theta_r"], P["thickness"], pr, pe,
+                      pdm=0.0, dt_h=300.0 / 3600.0, nthreads=cores, want_series=False)
+        return time.perf_counter() - t0
+
+    n0 = 64 * cores
+    t = run(n0)
+    n = int(max(n0, min(n0 * target_s / max(t, 1e-3), 2_000_000)))
+    n = (n // 64) * 64
+    t = run(n)
+    return {"value": n * T / t, "unit": "column-timesteps/s", "cores": cores, "kind": "port",
+            "sample": "%d columns x %d steps of the same synth_1 workload, fp64 C oracle, OpenMP, %.1f s" % (n, T, t)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--columns", type=int, default=1 << 20, help="columns per GPU")
+    ap.add_argument("--tile", type=int, default=1, help="time tiling of the 144-row synth_1 forcing")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU: the LGAR engine has no CPU fallback")
+    import torch.distributed as dist
+
+    import lgar_py_amd as lg
+    from lgar_py_amd import workloads as W
+
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    dtype = torch.float32 if args.dtype == "f32" else torch.float64
+    elem = 4 if args.dtype == "f32" else 8
+    N = args.columns
+    f = W.synth1_forcing(args.tile)
+    T = f.shape[0]
+    P = W.perturbed_columns(N, seed=rank)  # rank r holds columns [r*N, (r+1)*N) of the job; seed = shard index
+    sc = torch.tensor(W.forcing_scale(N, seed=1000 + rank), device=dev)
+    eng = lg.LgarEngine(P["alpha"], P["n"], P["ksat"], P["theta_e"], P["theta_r"], P["thickness"],
+                        dt_h=300.0 / 3600.0, ponded_depth_max=0.0, dtype=dtype, device=dev)
+    precip = (torch.tensor(f[:, 0], device=dev)[:, None] * sc[None, :]).to(dtype).contiguous()
+    pet = torch.zeros_like(precip)
+    # Keep the ensemble inside the reference's domain of validity (untimed set-up): a perturbed column whose
+    # run makes the reference raise (status != 0, e.g. the negative-pow-base path of insert_water)
+    # gets its soil re-drawn from the same distribution until no column faults.
+    resampled = 0
+    for it in range(1, 16):
+        eng.reset()
+        eng.forward(precip, pet, series=(), check=False)
+        bad = torch.nonzero(eng.status != 0).flatten()
+        if bad.numel() == 0:
+            break
+        resampled += int(bad.numel())
+        Q = W.perturbed_columns(int(bad.numel()), seed=(rank + 1) * 100003 + it)
+        for k, t in (("alpha", eng.alpha), ("n", eng.n), ("ksat", eng.ksat), ("theta_e", eng.theta_e), ("theta_r", eng.theta_r)):
+            t[:, bad] = torch.tensor(Q[k], device=dev).to(dtype)
+    out = {"runoff": torch.empty(T, N, dtype=dtype, device=dev), "percolation": torch.empty(T, N, dtype=dtype, device=dev)}
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def step(i=None):
+        eng.reset()
+        if i is not None:
+            ev[i][0].record()  # same stream as the kernel launch (torch's current stream)
+        eng.forward(precip, pet, series=("runoff", "percolation"), out=out, check=False)
+        if i is not None:
+            ev[i][1].record()
+        basin = out["runoff"].sum(dim=1, dtype=torch.float64)  # basin runoff per timestep [T]
+        if world > 1:
+            dist.all_reduce(basin)  # the only exchange of the path
+        return basin
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    basin = None
+    for i in range(args.steps):
+        basin = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else float("nan")
+    faulted = torch.tensor([int((eng.status != 0).sum().item())], device=dev)
+    if world > 1:
+        dist.all_reduce(faulted)
+
+    if rank == 0:
+        units = N * world * T * args.steps
+        b_alg = alg_bytes_per_col_step(elem, T)
+        achieved = b_alg * N * T / (kern_ms * 1e-3) / 1e9
+        line = {
+            "metric": "column-timesteps/sec", "value": units / elapsed, "unit": "column-timesteps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(args.steps, 1),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]/[3]: %d synthetic columns per GPU (Phillipsburg P-1..3 soils "
+                                   "+-10%% per column, forcing_data_synth_1 shape x U(0.5,1.5) per column), 3 layers, %s, "
+                                   "T=%d steps of 300 s per pass; pass = set_internal_states + T x forward + basin-runoff "
+                                   "reduction" % (N, args.dtype, T),
+                       "columns_per_gpu": N, "timesteps_per_pass": T, "columns_redrawn_to_stay_in_reference_domain": resampled, "parallelism": "columns sharded x%d" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "lgar_forward_kernel<%s,3,16>" % ("float" if elem == 4 else "double"),
+                         "kernel_ms": kern_ms, "alg_bytes_per_column_timestep": b_alg,
+                         "note": "path is VALU-transcendental bound (~1e3 flop/B), not HBM bound; see DESIGN.md"},
+            "faulted_columns": int(faulted.item()),
+            "basin_runoff_total_cm": float(basin.sum().item()),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -594,6 +594,7 @@ template <typename S, int NL, int FMAX> struct Column {
       S dzdt = S(R(0.0));
       if (val(delta_theta) > R(0.0)) {
         S g = geff(lk, theta_1, theta_2, G.nint);
+        if (is_nan(val(g))) status |= LGAR_ST_NAN;
         if (k == 0) {
           dzdt = R(1.0) / delta_theta * (lk.ksat * (g + h_p) / F.Z(i) + F.KK(i));
         } else {
@@ -620,6 +621,7 @@ template <typename S, int NL, int FMAX> struct Column {
     S delta_theta = l0.te - F.TH(0);
     S tau = G.dt_h * l0.ksat / delta_theta;
     S g = geff(l0, F.TH(0), l0.te, G.nint);
+    if (is_nan(val(g))) status |= LGAR_ST_NAN;
     S dry = R(0.5) * (tau + sq(tau * tau + R(4.0) * tau * g));
     return mn(P.cum[0], dry);
   }
@@ -666,7 +668,11 @@ template <typename S, int NL, int FMAX> struct Column {
     if (nxt_i >= nf) { status |= LGAR_ST_STRUCT; return; }
     const LayerK<S> lk = pick(P, kfp);
     S g = S(R(0.0));
+    // quirk: with a fully saturated one-front top layer right after a layer crossing, nxt_i is a front of the
+    // NEXT layer and Se > 1: the reference raises ValueError (negative pow base, physics/utils.py:25-27);
+    // here the NaN is flagged and the IEEE min below drops it (all ponded water infiltrates).
     if (nf != NL) g = geff(lk, F.TH(nxt_i), lk.te, G.nint);
+    if (is_nan(val(g))) status |= LGAR_ST_NAN | LGAR_ST_NEGBASE;
     S f_p;
     if (kfp == 0) {
       f_p = P.ksat[0] * (R(1.0) + (g + h_p) / F.Z(fdd));

@@ -1,0 +1,93 @@
+"""CPU: the C-ABI library builds for gfx950, loads, and exports every symbol include/lgar.h declares;
+struct layouts of the ctypes binding match the header; the product path refuses to run without a GPU
+(no CPU fallback) and never imports the oracle."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+
+def _declared_functions():
+    src = open(os.path.join(ROOT, "include", "lgar.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(lgar_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_symbols_exported():
+    from lgar_py_amd import _capi
+    lib = _capi.load()
+    names = _declared_functions()
+    assert "lgar_forward" in names and "lgar_state_init" in names and len(names) >= 7
+    for nm in names:
+        assert hasattr(lib, nm), nm
+    assert sorted(_capi.EXPORTS) == names
+    assert lib.lgar_fmax() == _capi.FMAX and lib.lgar_lmax() == _capi.LMAX
+    assert b"gfx950" in lib.lgar_version()
+
+
+def test_struct_layout_matches_header(tmp_path):
+    """Compile a tiny C program against include/lgar.h and compare sizeof/offsetof with ctypes."""
+    from lgar_py_amd import _capi
+    prog = tmp_path / "sz.c"
+    prog.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "lgar.h"\n'
+        'int main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %d %d %d %d\\n", sizeof(LgarDims), offsetof(LgarDims, dt_h),'
+        ' offsetof(LgarDims, giuh), offsetof(LgarDims, iter_cap), sizeof(LgarParams), sizeof(LgarState),'
+        ' sizeof(LgarForcing), sizeof(LgarStepOut), LGAR_FMAX, LGAR_LMAX, LGAR_GMAX, LGAR_NSCAL);return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)])
+    got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    D = _capi.LgarDims
+    want = [C.sizeof(D), D.dt_h.offset, D.giuh.offset, D.iter_cap.offset, C.sizeof(_capi.LgarParams),
+            C.sizeof(_capi.LgarState), C.sizeof(_capi.LgarForcing), C.sizeof(_capi.LgarStepOut), _capi.FMAX,
+            _capi.LMAX, _capi.GMAX, _capi.NSCAL]
+    assert got == want
+
+
+def test_no_cpu_fallback():
+    import torch
+    import lgar_py_amd as lg
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(lg.LgarError, match="no CPU fallback"):
+        lg.LgarEngine([1e-2] * 3, [1.5] * 3, [1.0] * 3, [0.4] * 3, [0.1] * 3, [10.0] * 3, n_columns=2)
+    with pytest.raises(lg.LgarError, match="no CPU fallback"):
+        lg.leaf_batch("geff", [0.1], [0.2], alpha=[0.01], n=[1.5], ksat=[1.0], theta_e=[0.4], theta_r=[0.1])
+
+
+def test_product_never_imports_oracle():
+    """oracle/ is test infrastructure: nothing under lgar-py_amd/ may reference it."""
+    pk = os.path.join(ROOT, "lgar-py_amd")
+    for dp, _, fs in os.walk(pk):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "oracle" not in txt.lower(), os.path.join(dp, f)
+    code = "import sys; sys.path.insert(0, %r); import lgar_py_amd; assert not any('oracle' in m for m in sys.modules), 'oracle imported'" % ROOT
+    subprocess.check_call([sys.executable, "-c", code])
+
+
+def test_workloads_match_fixtures():
+    from lgar_py_amd import workloads as W
+    g = np.load(os.path.join(GOLDEN, "synth1_phil.npz"))
+    assert np.array_equal(W.synth1_forcing(), g["forcing"])
+    assert W.synth1_forcing(3).shape == (432, 2)
+    for k in W.PARAM_KEYS:
+        assert np.array_equal(np.asarray(W.PHILLIPSBURG[k]), g[k])
+    P = W.perturbed_columns(1000, seed=0)
+    for k in W.PARAM_KEYS:
+        r = P[k] / np.asarray(W.PHILLIPSBURG[k])[:, None]
+        assert r.min() >= 0.9 and r.max() <= 1.1 and r.std() > 0.03
+    assert (P["theta_e"] > P["theta_r"]).all() and (P["n"] > 1.0).all()
+    s = W.forcing_scale(1000)
+    assert s.min() >= 0.5 and s.max() <= 1.5
+    for n, w in ((10, 3), (8_000_000, 8), (7, 8)):
+        b = [W.shard_bounds(n, w, r) for r in range(w)]
+        assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+        assert max(h - l for l, h in b) - min(h - l for l, h in b) <= 1
