@@ -147,11 +147,19 @@ template <typename S> __device__ __forceinline__ S geff(const LayerK<S> &l, S th
   S h2 = h_i + dh;
   S hdh = dh / R(2.0);
   for (int i = 0; i < nint; i++) {
-    S se2 = se_from_h(l, h2);
+    // rounding in the repeated h2 += dh can carry the last nodes past 0 (by ~1e-10 in fp64, by several cm in fp32
+    // when h_i ~ 1e6): a negative head is saturation (Se = 1, the |h| < 0.1 rule), never pow of a negative base
+    S se2 = (val(h2) < R(0.0)) ? S(R(1.0)) : se_from_h(l, h2);
     S k2 = k_from_se(l, se2);
     g = g + ((k1 + k2) * hdh);
     k1 = k2;
-    h2 = h2 + dh;
+    if (sizeof(R) == 4) {
+      // fp32: the reference's running sum h2 += dh drifts by ~nint ulps of h_i (cm-scale for very dry soil), and the
+      // last trapezoid (K -> Ksat as h -> h_f) dominates the integral; place the nodes directly instead
+      h2 = (i + 2 >= nint) ? h_f : h_i + R(i + 2) * dh;
+    } else {
+      h2 = h2 + dh;
+    }
   }
   return ab(g / l.ksat);
 }

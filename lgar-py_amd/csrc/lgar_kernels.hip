@@ -285,8 +285,8 @@ int32_t lgar_forward(const LgarDims *dims, const LgarParams *params, LgarState *
   if (rc) return rc;
   rc = check_state(params, state, status);
   if (rc) return rc;
+  if (dims->n_steps == 0) return 0;  // empty run: nothing to read
   if (!forcing || !forcing->precip || !forcing->pet) return LGAR_E_ARG;
-  if (dims->n_steps == 0) return 0;
   const unsigned grid = (unsigned)((dims->n_columns + WAVE - 1) / WAVE);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == LGAR_F64) {

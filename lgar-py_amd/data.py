@@ -1,0 +1,96 @@
+"""Inputs of the hot path: soil table, hard-coded vG parameter table, forcing series.
+
+Formats follow the reference's bundled files: forcing CSV `Time,P(mm/h),PET(mm/h)` (the
+synth files use `#Time` and end in blank lines; /root/reference/data/forcing_data_synth_1.txt), whitespace
+`.dat` soil tables with quoted texture names (/root/reference/data/vG_default_params.dat).  The loaders emit
+[T, N] column-fastest tensors ready for the kernels.
+"""
+import csv
+import shlex
+
+import numpy as np
+import torch
+
+# (alpha [1/cm], n, Ksat [cm/h]) by soil type: the values dpLGAR(cfg) takes its parameters from
+# (/root/reference/dpLGAR/data/utils.py:108-180, read_test_params); theta_e / theta_r come from the .dat file.
+VG_TABLE = np.array([
+    (0.01, 1.25, 0.612), (0.02, 1.42, 0.3348), (0.01, 1.47, 0.504), (0.03, 1.75, 4.32), (0.04, 3.18, 26.64),
+    (0.03, 1.21, 0.468), (0.02, 1.33, 0.54), (0.03, 1.45, 1.584), (0.01, 1.68, 1.836), (0.02, 1.32, 0.432),
+    (0.01, 1.52, 0.468), (0.01, 1.66, 0.756), (0.0031297, 1.6858, 0.45), (0.0083272, 1.299, 0.07),
+    (0.0037454, 1.6151, 0.45), (0.009567, 1.3579, 0.07), (0.005288, 1.5276, 0.02), (0.004467, 1.4585, 0.2),
+])
+
+
+def read_test_params(cfg=None):
+    """(alpha, n, Ksat) fp64 tensors of the 18-row table (data/utils.py:108)."""
+    t = torch.tensor(VG_TABLE, dtype=torch.float64)
+    return t[:, 0].clone(), t[:, 1].clone(), t[:, 2].clone()
+
+
+def read_soil_table(path):
+    """Whitespace-delimited soil table -> dict of numpy columns (Texture, theta_r, theta_e, alpha, n, m, Ks).
+    Row i is soil type i (0-based), as the reference indexes it (data/utils.py:66-67)."""
+    rows = []
+    with open(path) as f:
+        lines = [ln for ln in f.read().splitlines() if ln.strip()]
+    for ln in lines[1:]:
+        parts = shlex.split(ln)
+        rows.append((parts[0],) + tuple(float(v) for v in parts[1:7]))
+    cols = list(zip(*rows))
+    return dict(Texture=list(cols[0]), theta_r=np.array(cols[1]), theta_e=np.array(cols[2]), alpha=np.array(cols[3]),
+                n=np.array(cols[4]), m=np.array(cols[5]), Ks=np.array(cols[6]))
+
+
+def read_forcing(path, nsteps=None, mm_to_cm=0.1):
+    """Forcing file -> (times, x[T, 2]) with x = (precip, PET) in cm/h (data/Data.py:32-37)."""
+    times, p, e = [], [], []
+    with open(path, newline="") as f:
+        rd = csv.reader(f)
+        header = [h.strip().lstrip("#") for h in next(rd)]
+        it, ip, ie = header.index("Time"), header.index("P(mm/h)"), header.index("PET(mm/h)")
+        for row in rd:
+            if not row or not "".join(row).strip():
+                continue
+            times.append(row[it])
+            p.append(float(row[ip]))
+            e.append(float(row[ie]))
+            if nsteps is not None and len(times) >= nsteps:
+                break
+    x = np.stack([np.array(p), np.array(e)], axis=1) * mm_to_cm
+    return times, x
+
+
+def tile_forcing(x, n_columns, scale=None, device="cuda:0", dtype=torch.float64):
+    """x[T, 2] -> (precip[T, N], pet[T, N]) on the device, optionally scaled per column."""
+    x = torch.as_tensor(x, dtype=torch.float64, device=device)
+    T = x.shape[0]
+    s = torch.ones(n_columns, dtype=torch.float64, device=device) if scale is None else \
+        torch.as_tensor(scale, dtype=torch.float64, device=device)
+    precip = (x[:, 0:1] * s[None, :]).to(dtype).contiguous()
+    pet = (x[:, 1:2] * s[None, :]).to(dtype).contiguous() if scale is not None else \
+        x[:, 1:2].expand(T, n_columns).to(dtype).contiguous()
+    return precip, pet
+
+
+class Data(torch.utils.data.Dataset):
+    """Counterpart of dpLGAR.data.Data (data/Data.py:22-57): (x[2], y) per forcing row; y are observations if
+    cfg.data.observations is given, else zeros (the reference fills them with torch.rand, Data.py:43)."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.times, x = read_forcing(cfg.data.forcing_file, cfg.models.nsteps, cfg.conversions.mm_to_cm)
+        self.x = torch.tensor(x, dtype=torch.float64)
+        self.timestep_map = dict(enumerate(self.times))
+        self.y = torch.zeros(self.x.shape[0], dtype=torch.float64)
+
+    def __getitem__(self, i):
+        return self.x[i], self.y[i]
+
+    def __len__(self):
+        return self.x.shape[0]
+
+
+def calculate_nse(modeled, observed):
+    """Nash-Sutcliffe efficiency (data/metrics.py:4-8)."""
+    modeled, observed = np.asarray(modeled), np.asarray(observed)
+    return 1 - np.sum((observed - modeled) ** 2) / np.sum((observed - observed.mean()) ** 2)

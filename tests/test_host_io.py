@@ -1,0 +1,58 @@
+"""CPU: host-side config composition and input readers (no compute)."""
+import os
+
+import numpy as np
+
+from conftest import GOLDEN
+
+
+def write_soil_dat(path, rows=18):
+    from lgar_py_amd import data as D
+    te = {12: 0.4513, 13: 0.4773, 14: 0.4617}
+    tr = {12: 0.0648, 13: 0.0831, 14: 0.0668}
+    with open(path, "w") as f:
+        f.write("Texture\t        theta_r\ttheta_e\talpha(cm^-1)\tn\tm\tKs(cm/h)\n")
+        for i in range(rows):
+            a, n, k = D.VG_TABLE[i]
+            f.write('"T-%d"  \t\t%g \t%g\t%g \t%g\t%g\t%g\n' % (i, tr.get(i, 0.05), te.get(i, 0.4), a, n, 1 - 1 / n, k))
+    return path
+
+
+def write_forcing(path, x_cm_per_h, hash_header=False, step_min=60):
+    with open(path, "w") as f:
+        f.write(("#" if hash_header else "") + "Time,P(mm/h),PET(mm/h)\n")
+        for i, (p, e) in enumerate(x_cm_per_h):
+            f.write("2016-10-01 %02d:%02d:00,%r,%r\n" % ((i * step_min) // 60 % 24, (i * step_min) % 60, float(p) * 10.0, float(e) * 10.0))
+        if hash_header:
+            f.write("\n\n")
+    return path
+
+
+def test_config_keys_and_time_derivations(tmp_path):
+    from lgar_py_amd import config
+    cfg = config.load_config(cwd=str(tmp_path))
+    assert cfg.models.nsteps == 3000 and cfg.models.num_subcycles == 1 and cfg.models.subcycle_length_h == 1.0
+    assert cfg.data.layer_soil_type == [12, 13, 14] and cfg.data.ponded_depth_max == 2
+    assert cfg.data.forcing_file.startswith(str(tmp_path)) and cfg.constants.nint == 120
+    cfg2 = config.load_config(data="synth_1", models="five_minute", overrides={"models.endtime": 6.0})
+    assert cfg2.models.nsteps == 72 and abs(cfg2.models.subcycle_length_h - 300 / 3600) < 1e-15
+    cfg3 = config.load_config(models="base")
+    assert cfg3.models.num_subcycles == 12
+    cfg.data.soil_index = {"m": 4}
+    assert cfg.data.soil_index.m == 4
+
+
+def test_soil_table_and_forcing_readers(tmp_path):
+    from lgar_py_amd import data as D
+    soil = D.read_soil_table(write_soil_dat(str(tmp_path / "soil.dat")))
+    assert len(soil["Texture"]) == 18 and soil["Texture"][12] == "T-12"
+    assert soil["theta_e"][13] == 0.4773 and soil["theta_r"][14] == 0.0668
+    a, n, k = D.read_test_params()
+    assert float(a[12]) == 0.0031297 and float(n[13]) == 1.299 and float(k[14]) == 0.45
+    g = np.load(os.path.join(GOLDEN, "synth1_phil.npz"))
+    p = write_forcing(str(tmp_path / "f.txt"), g["forcing"], hash_header=True, step_min=5)
+    times, x = D.read_forcing(p)
+    assert len(times) == 144 and np.allclose(x, g["forcing"], rtol=0, atol=1e-15)
+    _, x2 = D.read_forcing(p, nsteps=10)
+    assert x2.shape == (10, 2)
+    assert abs(D.calculate_nse(np.array([1.0, 2.0, 3.0]), np.array([1.0, 2.0, 3.0])) - 1.0) < 1e-15
