@@ -286,6 +286,76 @@ template <typename S, int NL, int FMAX> struct Column {
     return idx;
   }
 
+  // theta(psi) and d theta / d psi of one layer in plain reals (no extra pow for the slope:
+  // theta' = -(theta - theta_r) m n (a psi)^n / (psi (1 + (a psi)^n)))
+  __device__ __forceinline__ static void theta_slope(R alpha, R n, R m, R te, R tr, R psi, R &th, R &dth) {
+    R ap = pw(alpha * psi, n);
+    R one_ap = R(1.0) + ap;
+    R op = pw(one_ap, m);
+    R span = R(1.0) / op * (te - tr);
+    th = span + tr;
+    dth = (psi > R(0.0)) ? -(span * m * n * ap) / (psi * one_ap) : R(0.0);
+  }
+
+  // search_mode 1: the same root -- psi with |sum_j thick_j (theta_j(psi) - dtheta_j) - prior_mass| <= tolerance --
+  // found by a bracketed Newton iteration (5-8 mass evaluations) instead of the reference's fixed-step decimal
+  // search (58-82 on average, Layer.py:275-317).  theta differs from the literal search by <= tolerance / thickness.
+  // Gradient semantics (dual numbers): psi_final = psi_init + constant, as in the reference (Layer.py:277-288).
+  __device__ __forceinline__ S theta_mass_balance_newton(int k, const LayerK<S> &lk, S psi0, S new_mass, S prior_mass,
+                                                         const S (&dth)[NL], const S (&dthick)[NL], S dth_k, S dthick_k) {
+    const R prior = val(prior_mass);
+    R psi = val(psi0);
+    R f = val(new_mass) - prior;
+    if (ab(f) <= Tol<R>::mass) return theta_from_h(lk, psi0);
+    R M = R(0.0), dM = R(0.0);
+    auto eval = [&](R x) {
+      R thk, dthk;
+      theta_slope(val(lk.alpha), val(lk.n), val(lk.m), val(lk.te), val(lk.tr), x, thk, dthk);
+      M = val(dthick_k) * (thk - val(dth_k));
+      dM = val(dthick_k) * dthk;
+#pragma unroll
+      for (int j = 0; j < NL - 1; j++)
+        if (j < k) {
+          R tj, dj;
+          theta_slope(val(P.alpha[j]), val(P.n[j]), val(P.m[j]), val(P.te[j]), val(P.tr[j]), x, tj, dj);
+          M += val(dthick[j]) * (tj - val(dth[j]));
+          dM += val(dthick[j]) * dj;
+        }
+    };
+    R lo = R(0.0), hi = R(-1.0);  // bracket f(lo) > 0 > f(hi); hi < 0: not found yet
+    bool lo_ok = false;
+    eval(psi);
+    f = M - prior;
+    for (int it = 0; it < 64; it++) {
+      if (ab(f) <= Tol<R>::mass) break;
+      if (f > R(0.0)) {
+        lo = psi;
+        lo_ok = true;
+      } else {
+        hi = psi;
+        if (!lo_ok) {
+          // is the target reachable at all?  mass at psi = 0 (saturation) needs no pow
+          R M0 = val(dthick_k) * (((val(lk.te) - val(lk.tr)) + val(lk.tr)) - val(dth_k));
+#pragma unroll
+          for (int j = 0; j < NL - 1; j++)
+            if (j < k) M0 += val(dthick[j]) * (((val(P.te[j]) - val(P.tr[j])) + val(P.tr[j])) - val(dth[j]));
+          if (M0 - prior <= Tol<R>::mass) { psi = R(0.0); break; }  // saturated: the reference walks psi -> 0 (Layer.py:287-316)
+          lo_ok = true;
+        }
+      }
+      R pn = (dM < R(0.0)) ? psi - f / dM : R(-1.0);
+      const bool inside = (pn > lo) && (hi < R(0.0) || pn < hi);
+      if (!inside) pn = (hi >= R(0.0)) ? R(0.5) * (lo + hi) : psi * R(2.0) + R(1.0);
+      if (pn == psi) break;  // step below resolution
+      psi = pn;
+      eval(psi);
+      f = M - prior;
+      if (it == 63) status |= LGAR_ST_ITERCAP;
+    }
+    const S psi_final = psi0 + (psi - val(psi0));
+    return theta_from_h(lk, psi_final);
+  }
+
   // theta_mass_balance, Layer.py:242-318 (+ recalculate_mass :211-240).  k = the front's layer;
   // dth/dthick hold the entries of the layers above (j < k), dth_k/dthick_k the front's own.
   __device__ __forceinline__ S theta_mass_balance(int k, const LayerK<S> &lk, S psi, S new_mass, S prior_mass, const S (&dth)[NL],
@@ -298,6 +368,7 @@ template <typename S, int NL, int FMAX> struct Column {
     R delta_mass_prev = delta_mass;
     int count_no_change = 0;
     if (delta_mass <= Tol<R>::mass) return theta_from_h(lk, psi);
+    if (G.search_mode != 0) return theta_mass_balance_newton(k, lk, psi, new_mass, prior_mass, dth, dthick, dth_k, dthick_k);
     long long it = 0;
     while (delta_mass > Tol<R>::mass) {
       if (++it > G.iter_cap) { status |= LGAR_ST_ITERCAP; break; }
@@ -337,15 +408,29 @@ template <typename S, int NL, int FMAX> struct Column {
       bool switched = false;
       R factor = R(1.0);
       S depth_new = F.Z(fdd);
+      // search_mode 1: the column mass is LINEAR in this one depth (slope = theta_fdd - theta_next, or theta_fdd for
+      // the last front of a layer), so all but the last two fixed steps of each up/down run are taken in one jump;
+      // the reference's loop then finishes on the true mass with its own termination test.
+      const bool nxt_same = (fdd + 1 < nf) && (F.layer(fdd + 1) == F.layer(fdd));
+      const R slope = nxt_same ? val(F.TH(fdd)) - val(F.TH(fdd + 1)) : val(F.TH(fdd));
+      const bool jump = (G.search_mode != 0) && (slope > R(0.0));
       long long it = 0;
       while (ab(err - Tol<R>::mass) > Tol<R>::mass) {
         if (++it > G.iter_cap) { status |= LGAR_ST_ITERCAP; break; }
         R before = val(depth_new);
         if (val(current_mass) < val(mass_timestep)) {
+          if (jump) {
+            R nsteps = (val(mass_timestep) - R(2.0) * Tol<R>::mass - val(current_mass)) / (slope * R(0.01) * factor);
+            if (nsteps > R(3.0)) depth_new = depth_new + (floor(nsteps) - R(2.0)) * (R(0.01) * factor);
+          }
           depth_new = depth_new + R(0.01) * factor;
           switched = false;
         } else {
           if (!switched) { switched = true; factor = factor * R(0.001); }
+          if (jump) {
+            R nsteps = (val(current_mass) - val(mass_timestep) - R(2.0) * Tol<R>::mass) / (slope * R(0.01) * factor);
+            if (nsteps > R(3.0)) depth_new = depth_new - (floor(nsteps) - R(2.0)) * (R(0.01) * factor);
+          }
           depth_new = depth_new - (R(0.01) * factor);
         }
         if (sizeof(R) == 4 && val(depth_new) == before && factor < R(1e-6)) break;  // fp32: step below resolution

@@ -35,12 +35,15 @@ def _forcing(g, ncol, sl=slice(None)):
     return f[:, 0:1].expand(T, ncol).contiguous(), f[:, 1:2].expand(T, ncol).contiguous()
 
 
+@pytest.mark.parametrize("mode", [1, 0], ids=["fast_search", "literal_search"])
 @pytest.mark.parametrize("name", golden_names())
-def test_fp64_trajectory_vs_reference_golden(name):
+def test_fp64_trajectory_vs_reference_golden(name, mode):
+    """Both search modes against the reference: 0 = its literal fixed-step line searches, 1 (the default, what
+    bench.py measures) = Newton / closed-form-jump searches to the same tolerances."""
     import lgar_py_amd as lg
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     ncol = 67  # one full wave + a ragged tail
-    eng = _engine(g, ncol, torch.float64)
+    eng = _engine(g, ncol, torch.float64, search_mode=mode)
     assert abs(float(eng.ending_volume[0]) - float(g["init_volume"])) <= 1e-9
     pr, pe = _forcing(g, ncol)
     out = eng.forward(pr, pe, series=lg.ACC_NAMES)
@@ -121,7 +124,7 @@ def test_heterogeneous_columns_vs_oracle_fp64():
     ro, pc, acc, st = O.run_columns(P["alpha"], P["n"], P["ksat"], P["theta_e"], P["theta_r"], P["thickness"], pr, pe,
                                     pdm=0.0, dt_h=300.0 / 3600.0)
     eng = lg.LgarEngine(P["alpha"], P["n"], P["ksat"], P["theta_e"], P["theta_r"], P["thickness"], dt_h=300.0 / 3600.0,
-                        ponded_depth_max=0.0, dtype=torch.float64)
+                        ponded_depth_max=0.0, dtype=torch.float64, search_mode=0)  # literal searches: same set as the oracle
     v0 = eng.ending_volume.clone()
     out = eng.forward(torch.tensor(pr), torch.tensor(pe), series=("runoff", "percolation"), check=False)
     # Some perturbed columns leave the reference's domain of validity (it raises ValueError: negative pow base in
