@@ -147,22 +147,51 @@ template <typename S> __device__ __forceinline__ S geff(const LayerK<S> &l, S th
   S h2 = h_i + dh;
   S hdh = dh / R(2.0);
   for (int i = 0; i < nint; i++) {
-    // rounding in the repeated h2 += dh can carry the last nodes past 0 (by ~1e-10 in fp64, by several cm in fp32
-    // when h_i ~ 1e6): a negative head is saturation (Se = 1, the |h| < 0.1 rule), never pow of a negative base
+    // rounding in the repeated h2 += dh can carry the last nodes past 0 (by ~1e-10 in fp64): a negative head is
+    // saturation (Se = 1, the |h| < 0.1 rule), never pow of a negative base
     S se2 = (val(h2) < R(0.0)) ? S(R(1.0)) : se_from_h(l, h2);
     S k2 = k_from_se(l, se2);
     g = g + ((k1 + k2) * hdh);
     k1 = k2;
-    if (sizeof(R) == 4) {
-      // fp32: the reference's running sum h2 += dh drifts by ~nint ulps of h_i (cm-scale for very dry soil), and the
-      // last trapezoid (K -> Ksat as h -> h_f) dominates the integral; place the nodes directly instead
-      h2 = (i + 2 >= nint) ? h_f : h_i + R(i + 2) * dh;
-    } else {
-      h2 = h2 + dh;
-    }
+    h2 = h2 + dh;
   }
   return ab(g / l.ksat);
 }
+
+// fp32 Geff: the same 121 nodes with Se(h) -> K(Se) fused per node.  With a = (alpha h)^n:
+//   Se = (1+a)^-m,  Se^(1/m) = 1/(1+a),  1 - Se^(1/m) = a/(1+a),  sqrt(Se) = (1+a)^(-m/2)
+// so K = Ksat (1+a)^(-m/2) (1 - (a/(1+a))^m)^2 needs 2 v_log_f32 + 3 v_exp_f32 and no division, instead of
+// 4 pow + sqrt + divide.  (The 1e-12 nudge of calc_k_from_se applies only for a <= 1e-8, i.e. |h| far below the
+// 0.1 cm cut where Se is 1 anyway.)  Nodes are placed directly (h_i + (i+1) dh, last node = h_f): the running
+// sum drifts by ~nint ulps of h_i, cm-scale for very dry soil, and the last trapezoid dominates the integral.
+#ifndef LGAR_NO_FUSED_GEFF
+template <> __device__ __forceinline__ float geff<float>(const LayerK<float> &l, float theta1, float theta2, int nint) {
+  const float se_i = se_from_theta(l, theta1);
+  const float se_f = se_from_theta(l, theta2);
+  const float h_i = h_from_se(l, se_i);
+  const float h_f = h_from_se(l, se_f);
+  const float dh = (h_f - h_i) / float(nint);
+  const float hdh = dh * 0.5f;
+  const float k_sat1 = k_from_se(l, 1.0f);  // K at Se == 1 (|h| < 0.1)
+  const float half_m = -0.5f * l.m;
+  float g = 0.0f;
+  float k1 = k_from_se(l, se_i);
+  for (int i = 0; i < nint; i++) {
+    const float h2 = (i + 1 >= nint) ? h_f : h_i + float(i + 1) * dh;
+    const float lg = __builtin_amdgcn_logf(l.alpha * h2);
+    const float a = __builtin_amdgcn_exp2f(l.n * lg);
+    const float l1 = __builtin_amdgcn_logf(1.0f + a);
+    const float sqrt_se = __builtin_amdgcn_exp2f(half_m * l1);
+    const float op = __builtin_amdgcn_exp2f(l.m * (l.n * lg - l1));
+    const float t = 1.0f - op;
+    float k2 = l.ksat * sqrt_se * (t * t);
+    k2 = (fabsf(h2) < 0.1f || h2 < 0.0f) ? k_sat1 : k2;
+    g = g + ((k1 + k2) * hdh);
+    k1 = k2;
+  }
+  return fabsf(g / l.ksat);
+}
+#endif
 // calc_aet, models/physics/lgar/aet.py:17-51 (0.75: GlobalParams.py:75; clamp upper bound = PET rate)
 template <typename S> __device__ __forceinline__ S aet_fn(const LayerK<S> &l, S pet, real_t<S> dt_h, S psi, real_t<S> wp_psi) {
   using R = real_t<S>;
