@@ -1,0 +1,109 @@
+"""Differentiable LGAR: torch autograd through the HIP kernels.
+
+The reference differentiates forward() by recording every scalar torch op
+(/root/reference/dpLGAR/agents/DifferentiableLGAR.py:119,163).  Here the vector-Jacobian product is assembled from
+forward-mode tangents computed on the GPU (csrc/lgar_tangent.hip): columns are independent, so one tangent launch
+with a one-hot direction over (alpha | n | Ksat, layer) yields d runoff_t / d p for every column's own parameter,
+contracted on the fly with the incoming gradient.  3 x L launches per backward, nothing stored per step.
+Line-search offsets are constants w.r.t. the parameters, exactly as in the reference (Layer.py:277-288, 683-696).
+"""
+import torch
+
+from .engine import LgarEngine
+
+KINDS = ("alpha", "n", "ksat")
+
+
+class LgarSeriesFunction(torch.autograd.Function):
+    """(alpha, n, ksat)[L, N] -> (runoff, percolation)[T, N] from a fresh state; differentiable in alpha/n/ksat."""
+
+    @staticmethod
+    def forward(ctx, alpha, n, ksat, theta_e, theta_r, thickness, precip, pet, engine_kw):
+        eng = LgarEngine(alpha.detach(), n.detach(), ksat.detach(), theta_e, theta_r, thickness, **engine_kw)
+        out = eng.forward(precip, pet, series=("runoff", "percolation"))
+        ctx.engine = eng
+        ctx.forcing = (precip, pet)
+        ctx.in_dtypes = (alpha.dtype, n.dtype, ksat.dtype)
+        return out["runoff"], out["percolation"]
+
+    @staticmethod
+    def backward(ctx, g_runoff, g_perc):
+        eng = ctx.engine
+        precip, pet = ctx.forcing
+        grads = []
+        for ki, kind in enumerate(KINDS):
+            if not ctx.needs_input_grad[ki]:
+                grads.append(None)
+                continue
+            g = torch.zeros(eng.L, eng.N, dtype=eng.dtype, device=eng.device)
+            for l in range(eng.L):
+                d = torch.zeros(eng.L, eng.N, dtype=eng.dtype, device=eng.device)
+                d[l] = 1.0
+                g[l], _, _ = eng.tangent({kind: d}, precip, pet, w_runoff=g_runoff, w_perc=g_perc)
+            grads.append(g.to(ctx.in_dtypes[ki]))
+        return (*grads, None, None, None, None, None, None)
+
+
+def lgar_series(alpha, n, ksat, theta_e, theta_r, thickness, precip, pet, **engine_kw):
+    """Differentiable run: parameters [L, N] (torch tensors, may require grad), forcing [T, N] -> runoff, percolation [T, N]."""
+    return LgarSeriesFunction.apply(alpha, n, ksat, theta_e, theta_r, thickness, precip, pet, engine_kw)
+
+
+class StepTape:
+    """Autograd for the reference's step-by-step calling convention (`model(x[i])` once per forcing row, loss at the
+    end of the epoch).  Every returned runoff/percolation value is a leaf that records the gradient it receives; when
+    the backward pass finishes, ONE batch of tangent launches over the recorded forcing series turns the recorded
+    weights into parameter gradients (accumulated into .grad like autograd would) -- O(T) work per epoch."""
+
+    def __init__(self, model):
+        self.model = model
+        self.reset()
+
+    def reset(self):
+        self.x = []          # forcing rows [N, 2] since the last set_internal_states()
+        self.w = {}          # (step, 0|1) -> gradient received
+        self.queued = False
+
+    def record(self, x_row, runoff_step, perc_step):
+        """x_row [N, 2]; returns leaf tensors standing for this step's runoff / percolation increments."""
+        t = len(self.x)
+        self.x.append(x_row.detach())
+        outs = []
+        for which, v in enumerate((runoff_step, perc_step)):
+            leaf = v.detach().clone().requires_grad_(True)
+            leaf.register_hook(lambda g, t=t, which=which: self._on_grad(t, which, g))
+            outs.append(leaf)
+        return outs
+
+    def _on_grad(self, t, which, g):
+        key = (t, which)
+        self.w[key] = self.w[key] + g.detach() if key in self.w else g.detach().clone()
+        if not self.queued:
+            self.queued = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._finalize)
+        return None
+
+    def _finalize(self):
+        self.queued = False
+        m = self.model
+        eng = m.engine
+        T, N = len(self.x), m.n_columns
+        X = torch.stack(self.x).to(eng.device, eng.dtype)  # [T, N, 2]
+        W = torch.zeros(2, T, N, dtype=eng.dtype, device=eng.device)
+        for (t, which), g in self.w.items():
+            W[which, t] = g.to(eng.device, eng.dtype).reshape(-1)
+        self.w = {}
+        precip, pet = X[:, :, 0].contiguous(), X[:, :, 1].contiguous()
+        ff = float(m.cfg.constants.frozen_factor)
+        for kind, plist in (("alpha", m.alpha), ("n", m.n), ("ksat", m.ksat)):
+            for l, p in enumerate(plist):
+                if not p.requires_grad:
+                    continue
+                d = torch.zeros(eng.L, eng.N, dtype=eng.dtype, device=eng.device)
+                d[l] = 1.0
+                g, _, _ = eng.tangent({kind: d}, precip, pet, w_runoff=W[0], w_perc=W[1])
+                if kind == "ksat":
+                    g = g / ff  # the Parameter already carries frozen_factor (models/dpLGAR.py:57)
+                g = g.to(torch.float64).to(p.device)
+                g = g.sum() if p.dim() == 0 else g
+                p.grad = g.to(p.dtype) if p.grad is None else p.grad + g.to(p.dtype)

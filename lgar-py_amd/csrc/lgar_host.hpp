@@ -1,0 +1,39 @@
+// lgar_host.hpp -- host-side helpers shared by the translation units of liblgar_hip.so
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "lgar_device.hpp"
+
+namespace lgar {
+
+template <typename R> inline Glob<R> make_glob(const LgarDims *d) {
+  Glob<R> G;
+  G.dt_h = (R)d->dt_h;
+  G.initial_psi = (R)d->initial_psi;
+  G.pdm = (R)d->ponded_depth_max;
+  G.wp_psi = (R)d->wilting_point_psi;
+  G.frozen = (R)d->frozen_factor;
+  for (int i = 0; i < LGAR_GMAX; i++) G.giuh[i] = (i < d->n_giuh) ? (R)d->giuh[i] : R(0);
+  G.nint = d->nint;
+  G.nsub = d->num_subcycles;
+  G.ng = d->n_giuh;
+  G.search_mode = d->search_mode;
+  G.iter_cap = d->iter_cap > 0 ? d->iter_cap : 2000000LL;
+  return G;
+}
+
+inline int check_dims(const LgarDims *d) {
+  if (!d) return LGAR_E_ARG;
+  if (d->n_columns <= 0 || d->n_layers != LGAR_LMAX) return LGAR_E_ARG;
+  if (d->n_giuh < 0 || d->n_giuh > LGAR_GMAX) return LGAR_E_ARG;
+  if (d->nint <= 0 || d->num_subcycles <= 0 || d->n_steps < 0) return LGAR_E_ARG;
+  if (!(d->dt_h > 0.0)) return LGAR_E_ARG;
+  return 0;
+}
+
+inline int launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : LGAR_E_LAUNCH;
+}
+
+}  // namespace lgar

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include "lgar_device.hpp"
+#include "lgar_host.hpp"
 
 namespace lgar {
 
@@ -190,31 +191,6 @@ template <typename R> __global__ void lgar_leaf_kernel(LeafArgs<R> a) {
   a.out[i] = r;
 }
 
-template <typename R> static Glob<R> make_glob(const LgarDims *d) {
-  Glob<R> G;
-  G.dt_h = (R)d->dt_h;
-  G.initial_psi = (R)d->initial_psi;
-  G.pdm = (R)d->ponded_depth_max;
-  G.wp_psi = (R)d->wilting_point_psi;
-  G.frozen = (R)d->frozen_factor;
-  for (int i = 0; i < LGAR_GMAX; i++) G.giuh[i] = (i < d->n_giuh) ? (R)d->giuh[i] : R(0);
-  G.nint = d->nint;
-  G.nsub = d->num_subcycles;
-  G.ng = d->n_giuh;
-  G.search_mode = d->search_mode;
-  G.iter_cap = d->iter_cap > 0 ? d->iter_cap : 2000000LL;
-  return G;
-}
-
-static int check_dims(const LgarDims *d) {
-  if (!d) return LGAR_E_ARG;
-  if (d->n_columns <= 0 || d->n_layers != LGAR_LMAX) return LGAR_E_ARG;
-  if (d->n_giuh < 0 || d->n_giuh > LGAR_GMAX) return LGAR_E_ARG;
-  if (d->nint <= 0 || d->num_subcycles <= 0 || d->n_steps < 0) return LGAR_E_ARG;
-  if (!(d->dt_h > 0.0)) return LGAR_E_ARG;
-  return 0;
-}
-
 static int check_state(const LgarParams *p, const LgarState *s, const int32_t *status) {
   if (!p || !s || !status) return LGAR_E_ARG;
   if (!p->alpha || !p->n || !p->ksat || !p->theta_e || !p->theta_r || !p->thickness) return LGAR_E_ARG;
@@ -242,11 +218,6 @@ static KArgs<R> make_args(const LgarDims *d, const LgarParams *p, LgarState *s, 
   a.status = status;
   a.G = make_glob<R>(d);
   return a;
-}
-
-static int launch_status() {
-  hipError_t e = hipGetLastError();
-  return e == hipSuccess ? 0 : LGAR_E_LAUNCH;
 }
 
 }  // namespace lgar
@@ -322,14 +293,6 @@ int32_t lgar_leaf_batch(int32_t op, int32_t n_items, const void *x, const void *
     return LGAR_E_ARG;
   }
   return launch_status();
-}
-
-int32_t lgar_forward_tangent(const LgarDims *dims, const LgarParams *params, const LgarParams *direction,
-                             const LgarForcing *forcing, const void *w_runoff, const void *w_perc, void *grad_out,
-                             void *tangent_runoff, int32_t *status, int32_t dtype, void *stream) {
-  (void)dims; (void)params; (void)direction; (void)forcing; (void)w_runoff; (void)w_perc; (void)grad_out;
-  (void)tangent_runoff; (void)status; (void)dtype; (void)stream;
-  return LGAR_E_ARG;  // implemented in lgar_tangent.hip (linked into the same library)
 }
 
 }  // extern "C"

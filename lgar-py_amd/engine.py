@@ -127,6 +127,33 @@ class LgarEngine:
             self.check_status()
         return res
 
+    def tangent(self, direction, precip, pet, w_runoff=None, w_perc=None, want_series=False):
+        """Forward-mode tangent from a FRESH state (set_internal_states) over the whole forcing series.
+
+        direction: {"alpha" | "n" | "ksat": [L, N] tensor} -- the parameter perturbation (missing = 0).
+        Returns (grad[N], tangent_runoff[T, N] or None, status[N]) with
+        grad[c] = sum_t w_runoff[t, c] * d runoff_t[c] + w_perc[t, c] * d percolation_t[c]."""
+        prep = lambda t: None if t is None else torch.as_tensor(t).to(self.device, self.dtype).contiguous()
+        precip, pet, w_runoff, w_perc = prep(precip), prep(pet), prep(w_runoff), prep(w_perc)
+        T = precip.shape[0]
+        dirs = {k: prep(direction.get(k)) for k in ("alpha", "n", "ksat")}
+        for k, v in dirs.items():
+            if v is not None and tuple(v.shape) != (self.L, self.N):
+                raise LgarError("direction[%r] must be [L, N]" % k)
+        ptr = lambda t: None if t is None else t.data_ptr()
+        dstruct = _capi.LgarParams(ptr(dirs["alpha"]), ptr(dirs["n"]), ptr(dirs["ksat"]), None, None, None)
+        grad = torch.zeros(self.N, dtype=self.dtype, device=self.device)
+        ser = torch.empty(T, self.N, dtype=self.dtype, device=self.device) if want_series else None
+        st = torch.zeros(self.N, dtype=torch.int32, device=self.device)
+        self.dims.n_steps = T
+        fo = _capi.LgarForcing(precip.data_ptr(), pet.data_ptr())
+        with torch.cuda.device(self.device):
+            rc = self.lib.lgar_forward_tangent(C.byref(self.dims), C.byref(self._params), C.byref(dstruct), C.byref(fo),
+                                               ptr(w_runoff), ptr(w_perc), grad.data_ptr(), ptr(ser), st.data_ptr(),
+                                               self._dt, self._stream())
+        _capi.check(rc, "lgar_forward_tangent")
+        return grad, ser, st
+
     def check_status(self):
         """Raise like the reference does (ValueError) if any column hit a physics fault."""
         bad = int((self.status != 0).sum().item())

@@ -73,6 +73,7 @@ class dpLGAR(nn.Module):
         self.global_params = None
         self.engine = None
         self.num_wetting_fronts = None
+        self.tape = None
         self.set_internal_states()
 
     # ----------------------------------------------------------------------------------------------
@@ -115,6 +116,8 @@ class dpLGAR(nn.Module):
                                  nint=int(cfg.constants.nint), giuh_ordinates=tuple(cfg.data.giuh_ordinates),
                                  dtype=self.dtype, device=self.device)
         self.c = self._soil_metrics(te, tr)
+        from .autograd import StepTape
+        self.tape = StepTape(self)
         self.num_wetting_fronts = self.calc_num_wetting_fronts()
         z = lambda: self._shape(torch.zeros(N, dtype=torch.float64, device=self.device))
         self.precip, self.PET, self.AET = z(), z(), z()
@@ -164,9 +167,19 @@ class dpLGAR(nn.Module):
         if x.shape[1] != N or x.shape[2] != 2:
             raise LgarError("forcing must be [2], [N, 2] or [T, N, 2] with N = %d" % N)
         out = self.engine.forward(x[:, :, 0], x[:, :, 1], series=ACC_NAMES[:8], check=False)
+        grad_mode = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         for nm in ACC_NAMES[:8]:
             step_sum = out[nm].to(torch.float64).sum(0)
+            if grad_mode and nm in ("runoff", "percolation"):
+                continue
             setattr(self, nm, getattr(self, nm) + self._shape(step_sum))
+        if grad_mode:
+            # autograd-connected accumulators: each forcing row's increments are recorded on the step tape; the
+            # parameter gradients are produced by tangent launches when the backward pass ends (autograd.StepTape)
+            for t in range(x.shape[0]):
+                r, p = self.tape.record(x[t], out["runoff"][t].to(torch.float64), out["percolation"][t].to(torch.float64))
+                self.runoff = self.runoff + self._shape(r)
+                self.percolation = self.percolation + self._shape(p)
         self.previous_precip = self._shape(self.engine.previous_precip.to(torch.float64))
         self.groundwater_discharge = self.groundwater_discharge * 0.0
         self.engine.check_status()  # raises ValueError like the reference, after the attributes are up to date

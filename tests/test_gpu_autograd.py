@@ -1,0 +1,157 @@
+"""GPU (-m gpu): the differentiable path (BASELINE configs[4]).  Gradients of loss = mean(runoff^2) w.r.t. the
+van Genuchten parameters, computed by forward-mode tangents in the HIP kernel, against (1) the gradients the
+reference's own torch autograd produced (golden fixtures grad_*.npz) and (2) central finite differences."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from test_host_io import write_forcing, write_soil_dat
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _setup(g, N, dtype=torch.float64, **kw):
+    T = g["forcing"].shape[0]
+    f = torch.tensor(g["forcing"], device="cuda")
+    pr = f[:, 0:1].expand(T, N).contiguous()
+    pe = f[:, 1:2].expand(T, N).contiguous()
+    P = {k: torch.tensor(np.repeat(g[k][:, None], N, 1), device="cuda", dtype=dtype) for k in
+         ("alpha", "n", "ksat", "theta_e", "theta_r", "thickness")}
+    ekw = dict(dt_h=float(g["dt_h"]), num_subcycles=int(g["num_subcycles"]), ponded_depth_max=float(g["pdm"]), dtype=dtype)
+    ekw.update(kw)
+    return P, pr, pe, ekw
+
+
+@pytest.mark.parametrize("name", ["grad_synth0_12h", "grad_synth1_phil"])
+@pytest.mark.parametrize("mode", [1, 0], ids=["fast_search", "literal_search"])
+def test_gradients_match_reference_autograd(name, mode):
+    from lgar_py_amd.autograd import lgar_series
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    N = 3
+    P, pr, pe, ekw = _setup(g, N, search_mode=mode)
+    for k in ("alpha", "n", "ksat"):
+        P[k].requires_grad_(True)
+    runoff, perc = lgar_series(P["alpha"], P["n"], P["ksat"], P["theta_e"], P["theta_r"], P["thickness"], pr, pe, **ekw)
+    assert runoff.requires_grad
+    loss = torch.mean(runoff[:, 0] ** 2)
+    assert abs(float(loss) - float(g["loss"])) <= 1e-9 * float(g["loss"])
+    loss.backward()
+    for k, ref in (("alpha", g["d_alpha"]), ("n", g["d_n"]), ("ksat", g["d_ksat"])):
+        got = P[k].grad[:, 0].cpu().numpy()
+        ref = np.nan_to_num(ref, nan=0.0)  # None in the reference = no dependence
+        scale = np.abs(ref).max()
+        assert np.abs(got - ref).max() <= 1e-6 * scale, (k, got, ref)
+        assert np.abs(P[k].grad[:, 1:].cpu().numpy()).max() == 0.0  # other columns do not enter the loss
+
+
+def test_tangent_matches_finite_differences():
+    """Independent check on perturbed columns: d(sum_t w_t runoff_t)/dp by tangents vs central differences (fp64)."""
+    import lgar_py_amd as lg
+    from lgar_py_amd import workloads as W
+    N = 64
+    Pn = W.perturbed_columns(N, seed=11)
+    sc = W.forcing_scale(N, 0.5, 1.0, seed=12)
+    f = W.synth1_forcing()
+    pr = torch.tensor(f[:, 0:1] * sc[None, :], device="cuda")
+    pe = torch.zeros_like(pr)
+    T = pr.shape[0]
+    w = torch.linspace(0.5, 1.5, T, device="cuda", dtype=torch.float64)[:, None].expand(T, N).contiguous()
+    kw = dict(dt_h=300.0 / 3600.0, ponded_depth_max=0.0, dtype=torch.float64)
+
+    def J(P):
+        e = lg.LgarEngine(P["alpha"], P["n"], P["ksat"], P["theta_e"], P["theta_r"], P["thickness"], **kw)
+        r = e.forward(pr, pe, series=("runoff",), check=False)["runoff"]
+        return (w * r).sum(0).cpu().numpy(), e.status.cpu().numpy()
+
+    base = lg.LgarEngine(Pn["alpha"], Pn["n"], Pn["ksat"], Pn["theta_e"], Pn["theta_r"], Pn["thickness"], **kw)
+    _, st0 = J(Pn)
+    checked = 0
+    for kind, l, h in (("alpha", 0, 1e-7), ("n", 0, 1e-6), ("ksat", 0, 1e-6), ("ksat", 1, 1e-6), ("n", 1, 1e-6)):
+        d = torch.zeros(3, N, dtype=torch.float64)
+        d[l] = 1.0
+        g, ser, st = base.tangent({kind: d}, pr, pe, w_runoff=w, want_series=True)
+        assert ser.shape == (T, N)
+        Pp = {k: v.copy() for k, v in Pn.items()}
+        Pm = {k: v.copy() for k, v in Pn.items()}
+        Pp[kind][l] += h * Pn[kind][l]
+        Pm[kind][l] -= h * Pn[kind][l]
+        jp, sp = J(Pp)
+        jm, sm = J(Pm)
+        fd = (jp - jm) / (2 * h * Pn[kind][l])
+        got = g.cpu().numpy()
+        ok = (st0 == 0) & (sp == 0) & (sm == 0) & (st.cpu().numpy() == 0)
+        # Reference-faithful gradients are NOT the true derivative wherever a line search is active: the psi / depth
+        # offsets found by the searches are constants to autograd (Layer.py:277-288, 683-696), and the
+        # response is only piecewise smooth (discrete front events).  Finite differences therefore agree for the
+        # columns/steps where no search contributes -- the bulk -- which is what is asserted here; exact agreement
+        # with the reference's own autograd is asserted in test_gradients_match_reference_autograd.
+        rel = np.abs(got - fd)[ok] / np.maximum(np.abs(fd[ok]), 1e-3 * np.abs(fd[ok]).max() + 1e-12)
+        assert np.median(rel) <= 1e-4, (kind, l, np.median(rel))
+        assert (rel <= 1e-2).mean() >= 0.5, (kind, l, (rel <= 1e-2).mean())
+        checked += int(ok.sum())
+    assert checked > 100
+
+
+def test_stepwise_model_backward_equals_series_backward(tmp_path):
+    """The reference's calling convention -- model(x[i]) per row, loss at the end, loss.backward(), optimizer.step() --
+    produces the same parameter gradients as the one-shot series function (and as the reference's autograd)."""
+    from lgar_py_amd import config
+    from lgar_py_amd.model import MassBalance, dpLGAR
+    g = np.load(os.path.join(GOLDEN, "grad_synth0_12h.npz"))
+    os.makedirs(tmp_path / "data", exist_ok=True)
+    soil = write_soil_dat(str(tmp_path / "data" / "soil.dat"))
+    forcing = write_forcing(str(tmp_path / "data" / "f.csv"), g["forcing"])
+    cfg = config.load_config(cwd=str(tmp_path), overrides={"data.forcing_file": forcing, "data.soil_params_file": soil,
+                                                           "data.ponded_depth_max": 0.0, "models.endtime": 12.0})
+    model = dpLGAR(cfg)
+    mb = MassBalance(cfg, model)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    opt.zero_grad()
+    ys = []
+    x = torch.tensor(g["forcing"])
+    for i in range(12):
+        runoff, _ = model(x[i])
+        ys.append(runoff)
+        mb.change_mass(model)
+    y = torch.stack(ys)
+    assert y.requires_grad
+    loss = torch.mean(y * y)
+    assert abs(float(loss) - float(g["loss"])) <= 1e-9 * float(g["loss"])
+    loss.backward()
+    for plist, ref in ((model.alpha, g["d_alpha"]), (model.n, g["d_n"]), (model.ksat, g["d_ksat"])):
+        ref = np.nan_to_num(ref, nan=0.0)
+        got = np.array([float(p.grad) for p in plist])
+        assert np.abs(got - ref).max() <= 1e-6 * np.abs(ref).max(), (got, ref)
+    before = float(model.alpha[0])
+    opt.step()
+    assert float(model.alpha[0]) != before
+
+
+def test_ensemble_gradients_config5_shape():
+    """BASELINE configs[4] at a reduced size: per-column (alpha, n, Ksat) ensemble, loss = mean runoff^2,
+    one backward = 9 tangent launches; gradients are per column and finite."""
+    from lgar_py_amd import workloads as W
+    from lgar_py_amd.autograd import lgar_series
+    N = 2048
+    E = W.ensemble_columns(N, seed=0)
+    f = W.synth1_forcing()
+    T = f.shape[0]
+    pr = torch.tensor(f[:, 0:1], device="cuda").expand(T, N).contiguous()
+    pe = torch.zeros_like(pr)
+    P = {k: torch.tensor(v, device="cuda") for k, v in E.items()}
+    for k in ("alpha", "n", "ksat"):
+        P[k].requires_grad_(True)
+    try:
+        runoff, _ = lgar_series(P["alpha"], P["n"], P["ksat"], P["theta_e"], P["theta_r"], P["thickness"], pr, pe,
+                                dt_h=300.0 / 3600.0, ponded_depth_max=0.0, dtype=torch.float64)
+    except ValueError:
+        pytest.skip("ensemble left the reference's domain of validity")
+    loss = torch.mean(runoff ** 2)
+    loss.backward()
+    for k in ("alpha", "n", "ksat"):
+        gk = P[k].grad
+        assert gk.shape == (3, N) and bool(torch.isfinite(gk).all())
+    assert float(P["ksat"].grad[0].abs().sum()) > 0
