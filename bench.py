@@ -86,11 +86,24 @@ def main():
     import lgar_py_amd as lg
     from lgar_py_amd import workloads as W
 
-    dev = torch.device("cuda", local_rank)
+    # one process per GPU; LGAR_DIST_BACKEND=gloo is a rehearsal mode (several ranks may then share one GPU)
+    backend = os.environ.get("LGAR_DIST_BACKEND", "nccl")
+    dev = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
+
+    def all_reduce(t, op=dist.ReduceOp.SUM):
+        if backend == "nccl":
+            dist.all_reduce(t, op=op)
+        else:  # gloo rehearsal: reduce on the host
+            h = t.cpu()
+            dist.all_reduce(h, op=op)
+            t.copy_(h)
 
     dtype = torch.float32 if args.dtype == "f32" else torch.float64
     elem = 4 if args.dtype == "f32" else 8
@@ -129,7 +142,7 @@ def main():
             ev[i][1].record()
         basin = out["runoff"].sum(dim=1, dtype=torch.float64)  # basin runoff per timestep [T]
         if world > 1:
-            dist.all_reduce(basin)  # the only exchange of the path
+            all_reduce(basin)  # the only exchange of the path
         return basin
 
     for _ in range(args.warmup):
@@ -149,12 +162,12 @@ def main():
     elapsed = time.perf_counter() - t0
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else float("nan")
     faulted = torch.tensor([int((eng.status != 0).sum().item())], device=dev)
     if world > 1:
-        dist.all_reduce(faulted)
+        all_reduce(faulted)
 
     if rank == 0:
         units = N * world * T * args.steps

@@ -19,8 +19,13 @@ class LgarSeriesFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, alpha, n, ksat, theta_e, theta_r, thickness, precip, pet, engine_kw):
+        engine_kw = dict(engine_kw)
+        check = engine_kw.pop("check", True)
+        status_out = engine_kw.pop("status_out", None)
         eng = LgarEngine(alpha.detach(), n.detach(), ksat.detach(), theta_e, theta_r, thickness, **engine_kw)
-        out = eng.forward(precip, pet, series=("runoff", "percolation"))
+        out = eng.forward(precip, pet, series=("runoff", "percolation"), check=check)
+        if status_out is not None:
+            status_out.append(eng.status)
         ctx.engine = eng
         ctx.forcing = (precip, pet)
         ctx.in_dtypes = (alpha.dtype, n.dtype, ksat.dtype)
@@ -45,7 +50,9 @@ class LgarSeriesFunction(torch.autograd.Function):
 
 
 def lgar_series(alpha, n, ksat, theta_e, theta_r, thickness, precip, pet, **engine_kw):
-    """Differentiable run: parameters [L, N] (torch tensors, may require grad), forcing [T, N] -> runoff, percolation [T, N]."""
+    """Differentiable run: parameters [L, N] (torch tensors, may require grad), forcing [T, N] -> runoff, percolation [T, N].
+    engine_kw: LgarEngine keywords, plus check=False to keep going when columns fault (mask them with the status
+    tensor appended to the list passed as status_out)."""
     return LgarSeriesFunction.apply(alpha, n, ksat, theta_e, theta_r, thickness, precip, pet, engine_kw)
 
 
