@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LGAR_FMAX 16  /* front slots per column (reference lists are unbounded; overflow -> status bit) */
+#define LGAR_FMAX 12  /* front slots per column (reference lists are unbounded, observed <= 8; overflow -> status bit) */
 #define LGAR_LMAX 3   /* soil layers compiled in (BASELINE configs: 3) */
 #define LGAR_GMAX 8   /* GIUH ordinates */
 #define LGAR_NSCAL (3 + LGAR_GMAX) /* scalars row count: ponded_water, previous_precip, ending_volume, giuh_queue[GMAX] */

@@ -220,12 +220,11 @@ template <typename R> struct Glob {
 
 // LDS view of one lane's fronts: element i of a field sits at field[i * WAVE]
 template <typename S> struct FrontsView {
-  S *z, *th, *ps, *kk, *dz;
+  S *z, *th, *ps, *dz;
   unsigned char *fl;
   __device__ __forceinline__ S &Z(int i) const { return z[i * WAVE]; }
   __device__ __forceinline__ S &TH(int i) const { return th[i * WAVE]; }
   __device__ __forceinline__ S &PS(int i) const { return ps[i * WAVE]; }
-  __device__ __forceinline__ S &KK(int i) const { return kk[i * WAVE]; }
   __device__ __forceinline__ S &DZ(int i) const { return dz[i * WAVE]; }
   __device__ __forceinline__ int layer(int i) const { return fl[i * WAVE] & 0x7f; }
   __device__ __forceinline__ bool bottom(int i) const { return (fl[i * WAVE] & LGAR_FLAG_BOTTOM) != 0; }
@@ -233,7 +232,7 @@ template <typename S> struct FrontsView {
     fl[i * WAVE] = (unsigned char)(layer | (bottom ? LGAR_FLAG_BOTTOM : 0));
   }
   __device__ __forceinline__ void copy(int dst, int src) const {
-    Z(dst) = Z(src); TH(dst) = TH(src); PS(dst) = PS(src); KK(dst) = KK(src); DZ(dst) = DZ(src);
+    Z(dst) = Z(src); TH(dst) = TH(src); PS(dst) = PS(src); DZ(dst) = DZ(src);
     fl[dst * WAVE] = fl[src * WAVE];
   }
 };
@@ -250,6 +249,12 @@ template <typename S, int NL, int FMAX> struct Column {
   int status;
   S ponded_water, previous_precip, ending_volume;
   S giuh_q[LGAR_GMAX];
+  // K(theta) is not kept per front: the reference refreshes it from theta for every front but the deepest at the end
+  // of each move (update_psi, Layer.py:1166-1170) and reads it only in calc_dzdt, so it is computed there, for moving
+  // fronts only.  k_deepest is the one K that is never refreshed (the domain's deepest front keeps its initial K);
+  // new_front_frozen marks a front created in the current sub-step, whose K carries frozen_factor (Layer.py:1410-1412).
+  S k_deepest;
+  bool new_front_frozen;
   // accumulators drained every forcing step (physics/MassBalance.py:45-53)
   S a_precip, a_pet, a_aet, a_infil, a_runoff, a_perc, a_giuh, a_disch;
 
@@ -587,7 +592,6 @@ template <typename S, int NL, int FMAX> struct Column {
       F.Z(i) = mass / (F.TH(i) - F.TH(nn));
       S se = se_from_theta(lk, F.TH(i));
       F.PS(i) = h_from_se(lk, se);
-      F.KK(i) = k_from_se(lk, se);
       // delete_front: the first front of THIS layer's list that is value-equal to `next`
       int j = lo;
       while (j < nf && F.layer(j) == k && !feq(j, nx)) j++;
@@ -616,7 +620,6 @@ template <typename S, int NL, int FMAX> struct Column {
       S overshot = F.Z(i) - F.Z(nx);
       S se = se_from_theta(lk, F.TH(i));
       F.PS(i) = h_from_se(lk, se);
-      F.KK(i) = k_from_se(lk, se);
       S theta_new = theta_from_h(ln, F.PS(i));
       S mbal = overshot * (F.TH(i) - F.TH(nx));
       S zc = mbal / (theta_new - F.TH(nn));
@@ -678,14 +681,19 @@ template <typename S, int NL, int FMAX> struct Column {
     return tot;
   }
 
-  // update_psi, Layer.py:1157-1174: psi and K from theta for every front but the deepest of the domain
+  // update_psi, Layer.py:1157-1174: psi from theta for every front but the deepest of the domain (K: see front_k)
   __device__ __forceinline__ void update_psi() {
     for (int i = 0; i < nf - 1; i++) {
       const LayerK<S> lk = pick(P, F.layer(i));
-      S se = se_from_theta(lk, F.TH(i));
-      F.PS(i) = h_from_se(lk, se);
-      F.KK(i) = k_from_se(lk, se);
+      F.PS(i) = h_from_se(lk, se_from_theta(lk, F.TH(i)));
     }
+  }
+
+  // K of front i as calc_dzdt / the state dump see it
+  __device__ __forceinline__ S front_k(int i, const LayerK<S> &lk) const {
+    S k = k_from_se(lk, se_from_theta(lk, F.TH(i)));
+    if (i == 0 && new_front_frozen) k = k * G.frozen;
+    return k;
   }
 
   // dpLGAR.move_wetting_front, models/dpLGAR.py:340-367.  Returns the bottom-boundary flux.
@@ -717,10 +725,11 @@ template <typename S, int NL, int FMAX> struct Column {
       if (val(delta_theta) > R(0.0)) {
         S g = geff(lk, theta_1, theta_2, G.nint);
         if (is_nan(val(g))) status |= LGAR_ST_NAN;
+        const S ki = front_k(i, lk);
         if (k == 0) {
-          dzdt = R(1.0) / delta_theta * (lk.ksat * (g + h_p) / F.Z(i) + F.KK(i));
+          dzdt = R(1.0) / delta_theta * (lk.ksat * (g + h_p) / F.Z(i) + ki);
         } else {
-          S den = S(R(0.0)) + (F.Z(i) - cum_prev(k)) / F.KK(i);
+          S den = S(R(0.0)) + (F.Z(i) - cum_prev(k)) / ki;
 #pragma unroll
           for (int j = 0; j < NL - 1; j++)
             if (j < k) {
@@ -771,9 +780,8 @@ template <typename S, int NL, int FMAX> struct Column {
     F.Z(0) = dry_depth;
     F.TH(0) = theta_new;
     F.set_flag(0, 0, to_bottom);
-    S se = se_from_theta(l0, theta_new);
-    F.PS(0) = h_from_se(l0, se);
-    F.KK(0) = k_from_se(l0, se) * G.frozen;
+    F.PS(0) = h_from_se(l0, se_from_theta(l0, theta_new));
+    new_front_frozen = true;
     F.DZ(0) = S(R(0.0));
   }
 
@@ -837,13 +845,14 @@ template <typename S, int NL, int FMAX> struct Column {
   __device__ __forceinline__ void init_state() {
     nf = NL;
     status = 0;
+    new_front_frozen = false;
 #pragma unroll
     for (int k = 0; k < NL; k++) {
       const LayerK<S> lk = pick_static(P, k);
       F.Z(k) = P.cum[k];
       F.TH(k) = theta_from_h(lk, S(G.initial_psi));
       F.PS(k) = S(G.initial_psi);
-      F.KK(k) = k_from_se(lk, se_from_theta(lk, F.TH(k)));
+      if (k == NL - 1) k_deepest = k_from_se(lk, se_from_theta(lk, F.TH(k)));
       F.DZ(k) = S(R(0.0));
       F.set_flag(k, k, true);
     }
@@ -864,6 +873,7 @@ template <typename S, int NL, int FMAX> struct Column {
     S ending_volume_sub = ending_volume;
     for (int sub = 0; sub < G.nsub; sub++) {
       if (status & (LGAR_ST_BOTTOM | LGAR_ST_OVERFLOW | LGAR_ST_STRUCT)) return;  // dead column
+      new_front_frozen = false;
       S precip_sub = precip * dt;
       S pet_sub = pet * dt;
       S ponded_depth_sub = precip_sub + ponded_water;

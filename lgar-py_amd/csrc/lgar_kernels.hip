@@ -29,7 +29,7 @@ template <typename R> struct KArgs {
 };
 
 template <typename S, int FMAX> struct WaveLDS {
-  S f[5][FMAX][WAVE];
+  S f[4][FMAX][WAVE];
   unsigned char fl[FMAX][WAVE];
 };
 
@@ -57,8 +57,7 @@ template <typename S> __device__ __forceinline__ FrontsView<S> make_view(S *f, u
   F.z = f + 0 * fmax * WAVE + lane;
   F.th = f + 1 * fmax * WAVE + lane;
   F.ps = f + 2 * fmax * WAVE + lane;
-  F.kk = f + 3 * fmax * WAVE + lane;
-  F.dz = f + 4 * fmax * WAVE + lane;
+  F.dz = f + 3 * fmax * WAVE + lane;
   F.fl = fl + lane;
   return F;
 }
@@ -71,7 +70,7 @@ __device__ __forceinline__ void store_state(const KArgs<R> &a, size_t c, const C
     a.depth[i * N + c] = live ? col.F.Z(i) : R(0);
     a.theta[i * N + c] = live ? col.F.TH(i) : R(0);
     a.psi[i * N + c] = live ? col.F.PS(i) : R(0);
-    a.k[i * N + c] = live ? col.F.KK(i) : R(0);
+    a.k[i * N + c] = live ? ((i < col.nf - 1) ? col.front_k(i, pick(col.P, col.F.layer(i))) : col.k_deepest) : R(0);
     a.dzdt[i * N + c] = live ? col.F.DZ(i) : R(0);
     a.flags[i * N + c] = live ? col.F.fl[i * WAVE] : (uint8_t)0;
   }
@@ -103,7 +102,7 @@ __global__ __launch_bounds__(WAVE) void lgar_init_kernel(KArgs<R> a) {
 
 // T x (dpLGAR.forward + MassBalance.change_mass) for every column; time loop inside the kernel
 template <typename R, int NL, int FMAX>
-__global__ __launch_bounds__(WAVE) void lgar_forward_kernel(KArgs<R> a) {
+__global__ __launch_bounds__(WAVE, (sizeof(R) == 4) ? 3 : 1) void lgar_forward_kernel(KArgs<R> a) {
   __shared__ WaveLDS<R, FMAX> lds;
   const int lane = threadIdx.x;
   const size_t c = (size_t)blockIdx.x * WAVE + lane;
@@ -120,7 +119,6 @@ __global__ __launch_bounds__(WAVE) void lgar_forward_kernel(KArgs<R> a) {
     col.F.Z(i) = a.depth[i * N + c];
     col.F.TH(i) = a.theta[i * N + c];
     col.F.PS(i) = a.psi[i * N + c];
-    col.F.KK(i) = a.k[i * N + c];
     col.F.DZ(i) = a.dzdt[i * N + c];
     col.F.fl[i * WAVE] = a.flags[i * N + c];
   }
@@ -130,6 +128,8 @@ __global__ __launch_bounds__(WAVE) void lgar_forward_kernel(KArgs<R> a) {
 #pragma unroll
   for (int i = 0; i < LGAR_GMAX; i++) col.giuh_q[i] = a.scalars[(3 + i) * N + c];
   col.status = a.status[c];
+  col.k_deepest = (nf > 0) ? a.k[(size_t)(nf - 1) * N + c] : R(0);
+  col.new_front_frozen = false;
   col.drain();
   R tot[8];
 #pragma unroll

@@ -28,7 +28,7 @@ template <typename R> struct TArgs {
 
 template <typename R, int NL, int FMAX> __global__ __launch_bounds__(WAVE) void lgar_tangent_kernel(TArgs<R> a) {
   using S = Dual<R>;
-  __shared__ S lds_f[5 * FMAX * WAVE];
+  __shared__ S lds_f[4 * FMAX * WAVE];
   __shared__ unsigned char lds_fl[FMAX * WAVE];
   const int lane = threadIdx.x;
   const size_t c = (size_t)blockIdx.x * WAVE + lane;
@@ -54,8 +54,7 @@ template <typename R, int NL, int FMAX> __global__ __launch_bounds__(WAVE) void 
   F.z = lds_f + 0 * FMAX * WAVE + lane;
   F.th = lds_f + 1 * FMAX * WAVE + lane;
   F.ps = lds_f + 2 * FMAX * WAVE + lane;
-  F.kk = lds_f + 3 * FMAX * WAVE + lane;
-  F.dz = lds_f + 4 * FMAX * WAVE + lane;
+  F.dz = lds_f + 3 * FMAX * WAVE + lane;
   F.fl = lds_fl + lane;
   Column<S, NL, FMAX> col(P, a.G, F);
   col.init_state();

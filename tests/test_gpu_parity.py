@@ -57,6 +57,8 @@ def test_fp64_trajectory_vs_reference_golden(name, mode):
     assert _rel(fr["depth"][:nf, 0], g["fronts"][-1, :nf, 0]).max() <= 1e-6
     assert _rel(fr["theta"][:nf, 0], g["fronts"][-1, :nf, 1]).max() <= 1e-6
     assert _rel(fr["psi"][:nf, 0], g["fronts"][-1, :nf, 2], 1e-3).max() <= 1e-5
+    assert _rel(fr["k"][:nf, 0], g["fronts"][-1, :nf, 3], 1e-12).max() <= 1e-5   # K(theta), deepest front keeps its initial K
+    assert _rel(fr["dzdt"][:nf, 0], g["fronts"][-1, :nf, 4], 1e-9).max() <= 1e-5
     assert (fr["layer"][:nf, 0] == g["front_layer"][-1, :nf]).all()
     assert (fr["to_bottom"][:nf, 0] == g["front_bottom"][-1, :nf]).all()
     # run totals (what MassBalance accumulates)
