@@ -34,6 +34,20 @@ def alg_bytes_per_col_step(elem, T, L=3, fmax=16):
     return 4 * elem + b_col / T
 
 
+def measured_traffic(N, T, dtype):
+    """HBM bytes per launch from the committed PMC passes (profiles/*/traffic.json), when they were taken on exactly
+    this workload; FETCH_SIZE corrected x2 as MI355X_MICROARCH.md prescribes for gfx950.  None otherwise."""
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    for r in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        f = os.path.join(pdir, r, "traffic.json")
+        if os.path.exists(f):
+            t = json.load(open(f))
+            if (t.get("columns"), t.get("timesteps"), t.get("dtype")) == (N, T, dtype):
+                best = (2 * t["FETCH_SIZE_KB"] + t["WRITE_SIZE_KB"]) * 1024
+    return best
+
+
 def cpu_baseline(target_s=12.0):
     """Oracle (C restatement, fp64, OpenMP over columns) timed on this host on a bounded sample of the
     same workload.  A reported baseline, never the thing measured above."""
@@ -183,10 +197,13 @@ def main():
                                    "reduction" % (N, args.dtype, T),
                        "columns_per_gpu": N, "timesteps_per_pass": T, "columns_redrawn_to_stay_in_reference_domain": resampled, "parallelism": "columns sharded x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(N, T, args.dtype),
+                         "traffic_note": "bytes per launch from separate rocprofv3 --pmc passes (profiles/r01/traffic.json), not live",
+                         "algorithmic_bytes_per_launch": b_alg * N * T,
                          "kernel": "lgar_forward_kernel<%s,3,16>" % ("float" if elem == 4 else "double"),
                          "kernel_ms": kern_ms, "alg_bytes_per_column_timestep": b_alg,
-                         "note": "path is VALU-transcendental bound (~1e3 flop/B), not HBM bound; see DESIGN.md"},
+                         "note": "path is VALU bound, not HBM bound (~1e3 flop/B; SQ_ACTIVE_INST_VALU ~97% of SIMD cycles in "
+                                 "profiles/r01/bench_v4_pmc_summary.txt); see DESIGN.md"},
             "faulted_columns": int(faulted.item()),
             "basin_runoff_total_cm": float(basin.sum().item()),
         }
