@@ -57,33 +57,34 @@ def lgar_series(alpha, n, ksat, theta_e, theta_r, thickness, precip, pet, **engi
 
 
 class StepTape:
-    """Autograd for the reference's step-by-step calling convention (`model(x[i])` once per forcing row, loss at the
-    end of the epoch).  Every returned runoff/percolation value is a leaf that records the gradient it receives; when
-    the backward pass finishes, ONE batch of tangent launches over the recorded forcing series turns the recorded
-    weights into parameter gradients (accumulated into .grad like autograd would) -- O(T) work per epoch."""
+    """Autograd for the reference's calling convention (`model(x[i])` once per forcing row -- or a whole [T, N, 2] block --
+    with the loss taken at the end of the epoch).  Every returned runoff/percolation block is a leaf that records the
+    gradient it receives; when the backward pass finishes, ONE batch of tangent launches over the recorded forcing
+    series turns the recorded weights into parameter gradients (accumulated into .grad like autograd would) --
+    O(T) work per epoch, nothing stored per step but the forcing rows."""
 
     def __init__(self, model):
         self.model = model
         self.reset()
 
     def reset(self):
-        self.x = []          # forcing rows [N, 2] since the last set_internal_states()
-        self.w = {}          # (step, 0|1) -> gradient received
+        self.x = []          # forcing chunks [Tc, N, 2] since the last set_internal_states()
+        self.w = {}          # (chunk, 0|1) -> gradient received, [Tc, N]
         self.queued = False
 
-    def record(self, x_row, runoff_step, perc_step):
-        """x_row [N, 2]; returns leaf tensors standing for this step's runoff / percolation increments."""
-        t = len(self.x)
-        self.x.append(x_row.detach())
+    def record(self, x_chunk, runoff_chunk, perc_chunk):
+        """x_chunk [Tc, N, 2]; runoff/perc [Tc, N].  Returns leaf tensors standing for this chunk's per-step values."""
+        ci = len(self.x)
+        self.x.append(x_chunk.detach())
         outs = []
-        for which, v in enumerate((runoff_step, perc_step)):
+        for which, v in enumerate((runoff_chunk, perc_chunk)):
             leaf = v.detach().clone().requires_grad_(True)
-            leaf.register_hook(lambda g, t=t, which=which: self._on_grad(t, which, g))
+            leaf.register_hook(lambda g, ci=ci, which=which: self._on_grad(ci, which, g))
             outs.append(leaf)
         return outs
 
-    def _on_grad(self, t, which, g):
-        key = (t, which)
+    def _on_grad(self, ci, which, g):
+        key = (ci, which)
         self.w[key] = self.w[key] + g.detach() if key in self.w else g.detach().clone()
         if not self.queued:
             self.queued = True
@@ -94,11 +95,16 @@ class StepTape:
         self.queued = False
         m = self.model
         eng = m.engine
-        T, N = len(self.x), m.n_columns
-        X = torch.stack(self.x).to(eng.device, eng.dtype)  # [T, N, 2]
-        W = torch.zeros(2, T, N, dtype=eng.dtype, device=eng.device)
-        for (t, which), g in self.w.items():
-            W[which, t] = g.to(eng.device, eng.dtype).reshape(-1)
+        X = torch.cat(self.x).to(eng.device, eng.dtype)  # [T, N, 2]
+        T = X.shape[0]
+        W = torch.zeros(2, T, eng.N, dtype=eng.dtype, device=eng.device)
+        t0 = 0
+        for ci, xc in enumerate(self.x):
+            for which in (0, 1):
+                g = self.w.get((ci, which))
+                if g is not None:
+                    W[which, t0:t0 + xc.shape[0]] = g.to(eng.device, eng.dtype).reshape(xc.shape[0], eng.N)
+            t0 += xc.shape[0]
         self.w = {}
         precip, pet = X[:, :, 0].contiguous(), X[:, :, 1].contiguous()
         ff = float(m.cfg.constants.frozen_factor)

@@ -173,18 +173,18 @@ class dpLGAR(nn.Module):
             if grad_mode and nm in ("runoff", "percolation"):
                 continue
             setattr(self, nm, getattr(self, nm) + self._shape(step_sum))
+        r_series, p_series = out["runoff"], out["percolation"]
         if grad_mode:
-            # autograd-connected accumulators: each forcing row's increments are recorded on the step tape; the
+            # autograd-connected outputs: this block's per-step runoff / percolation are recorded on the step tape; the
             # parameter gradients are produced by tangent launches when the backward pass ends (autograd.StepTape)
-            for t in range(x.shape[0]):
-                r, p = self.tape.record(x[t], out["runoff"][t].to(torch.float64), out["percolation"][t].to(torch.float64))
-                self.runoff = self.runoff + self._shape(r)
-                self.percolation = self.percolation + self._shape(p)
+            r_series, p_series = self.tape.record(x, out["runoff"].to(torch.float64), out["percolation"].to(torch.float64))
+            self.runoff = self.runoff + self._shape(r_series.sum(0))
+            self.percolation = self.percolation + self._shape(p_series.sum(0))
         self.previous_precip = self._shape(self.engine.previous_precip.to(torch.float64))
         self.groundwater_discharge = self.groundwater_discharge * 0.0
         self.engine.check_status()  # raises ValueError like the reference, after the attributes are up to date
         if series_mode:
-            return out["runoff"], out["percolation"]
+            return r_series, p_series
         return self.runoff, self.percolation
 
     # state the agent / MassBalance read -----------------------------------------------------------

@@ -159,3 +159,42 @@ def test_ensemble_gradients_config5_shape():
         assert gk.shape == (3, N) and bool(torch.isfinite(gk[:, ok]).all())
         assert float(gk[:, ~ok].abs().sum()) == 0.0
     assert float(P["ksat"].grad[0].abs().sum()) > 0
+
+
+def test_agent_twin_experiment_reduces_loss(tmp_path):
+    """Agent counterpart (agents/DifferentiableLGAR.py:94-172): synthetic-truth runoff, perturbed Ksat, a few Adam epochs."""
+    from lgar_py_amd import config
+    from lgar_py_amd import workloads as W
+    from lgar_py_amd.agent import DifferentiableLGAR, RangeBoundLoss
+    from lgar_py_amd.model import dpLGAR
+    f = W.synth1_forcing()
+    os.makedirs(tmp_path / "data", exist_ok=True)
+    soil = write_soil_dat(str(tmp_path / "data" / "soil.dat"))
+    forcing = write_forcing(str(tmp_path / "data" / "f.csv"), f, step_min=5)
+    ov = {"data.forcing_file": forcing, "data.soil_params_file": soil, "models.hyperparameters.epochs": 6,
+          "models.hyperparameters.learning_rate": 0.02, "models.hyperparameters.warmup": 0}
+    cfg = config.load_config(data="synth_1", models="five_minute", cwd=str(tmp_path), overrides=ov)
+    with torch.no_grad():
+        truth = dpLGAR(cfg)
+        obs, _ = truth(torch.tensor(f)[:, None, :])
+        obs = obs[:, 0].cpu()
+    assert float(obs.sum()) > 0.1
+    for stepwise in (False, True):
+        agent = DifferentiableLGAR(cfg, observations=obs, stepwise=stepwise, log=lambda s: None)
+        with torch.no_grad():
+            agent.model.ksat[0].mul_(0.6)  # start from a wrong top-layer Ksat
+        for p in list(agent.model.alpha) + list(agent.model.n):
+            p.requires_grad_(False)        # Adam moves every parameter by ~lr per step: only Ksat is trained here
+        agent.model.set_internal_states()
+        agent.cfg.models.hyperparameters.epochs = 6 if not stepwise else 2
+        agent.run()
+        h = agent.history
+        assert all(np.isfinite(e["loss"]) for e in h)
+        assert h[-1]["loss"] < h[0]["loss"], h
+        assert float(agent.model.ksat[0]) > 0.27
+    rb = RangeBoundLoss([0.0015, 1.0, 1e-6, 0.0], [0.015, 5.0, 30, 10.0])
+    m = agent.model
+    assert float(rb([m.alpha, m.n, m.ksat, m.ponded_depth_max])) == 0.0
+    with torch.no_grad():
+        m.alpha[0].fill_(0.02)
+    assert abs(float(rb([m.alpha, m.n, m.ksat, m.ponded_depth_max])) - 0.005) < 1e-12
