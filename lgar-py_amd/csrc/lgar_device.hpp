@@ -28,7 +28,13 @@ template <typename S> using real_t = typename Real<S>::type;
 
 __device__ __forceinline__ double val(double x) { return x; }
 __device__ __forceinline__ float val(float x) { return x; }
-__device__ __forceinline__ double pw(double x, double y) { return pow(x, y); }
+#ifndef LGAR_F64_FAST_POW
+__device__ __forceinline__ double pw(double x, double y) { return pow(x, y); }  // ocml, < 1 ulp
+#else
+// exp2(y log2 x): ~|y log2 x| ulps (1e-14 relative here).  Measured +5 % on the fp64 kernel once Geff is fused, with
+// the same parity: not worth leaving the < 1 ulp pow for the state updates, so it is off by default.
+__device__ __forceinline__ double pw(double x, double y) { return exp2(y * log2(x)); }
+#endif
 // fp32: v_log_f32 / v_exp_f32 (quarter-rate transcendentals), ~2-3 ulp for the exponents used here
 __device__ __forceinline__ float pw(float x, float y) { return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)); }
 __device__ __forceinline__ double sq(double x) { return sqrt(x); }
@@ -165,32 +171,54 @@ template <typename S> __device__ __forceinline__ S geff(const LayerK<S> &l, S th
 // 0.1 cm cut where Se is 1 anyway.)  Nodes are placed directly (h_i + (i+1) dh, last node = h_f): the running
 // sum drifts by ~nint ulps of h_i, cm-scale for very dry soil, and the last trapezoid dominates the integral.
 #ifndef LGAR_NO_FUSED_GEFF
-template <> __device__ __forceinline__ float geff<float>(const LayerK<float> &l, float theta1, float theta2, int nint) {
-  const float se_i = se_from_theta(l, theta1);
-  const float se_f = se_from_theta(l, theta2);
-  const float h_i = h_from_se(l, se_i);
-  const float h_f = h_from_se(l, se_f);
-  const float dh = (h_f - h_i) / float(nint);
-  const float hdh = dh * 0.5f;
-  const float k_sat1 = k_from_se(l, 1.0f);  // K at Se == 1 (|h| < 0.1)
-  const float half_m = -0.5f * l.m;
-  float g = 0.0f;
-  float k1 = k_from_se(l, se_i);
+// Fused Geff for plain reals: the same 121 nodes with Se(h) -> K(Se) fused per node.  With a = (alpha h)^n:
+//   Se = (1+a)^-m,  Se^(1/m) = 1/(1+a),  1 - Se^(1/m) = a/(1+a),  sqrt(Se) = (1+a)^(-m/2)
+// so K = Ksat (1+a)^(-m/2) (1 - (a/(1+a))^m)^2 needs 2 log2 + 3 exp2 and no division, instead of 4 pow + sqrt +
+// divide.  (The 1e-12 nudge of calc_k_from_se applies only for a <= 1e-8, i.e. |h| far below the 0.1 cm cut where Se
+// is 1 anyway.)  fp32 places the nodes directly (h_i + (i+1) dh, last node = h_f): its running sum drifts by ~nint
+// ulps of h_i, cm-scale for very dry soil, and the last trapezoid dominates the integral; fp64 keeps the
+// reference's running sum h2 += dh.
+__device__ __forceinline__ float lg2(float x) { return __builtin_amdgcn_logf(x); }
+__device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ double lg2(double x) { return log2(x); }
+__device__ __forceinline__ double ex2(double x) { return exp2(x); }
+
+template <typename R> __device__ __forceinline__ R geff_fused(const LayerK<R> &l, R theta1, R theta2, int nint) {
+  const R se_i = se_from_theta(l, theta1);
+  const R se_f = se_from_theta(l, theta2);
+  const R h_i = h_from_se(l, se_i);
+  const R h_f = h_from_se(l, se_f);
+  const R dh = (h_f - h_i) / R(nint);
+  const R hdh = dh / R(2.0);
+  const R k_sat1 = k_from_se(l, R(1.0));  // K at Se == 1 (|h| < 0.1)
+  const R half_m = R(-0.5) * l.m;
+  R g = R(0.0);
+  R k1 = k_from_se(l, se_i);
+  R h2 = h_i + dh;
   for (int i = 0; i < nint; i++) {
-    const float h2 = (i + 1 >= nint) ? h_f : h_i + float(i + 1) * dh;
-    const float lg = __builtin_amdgcn_logf(l.alpha * h2);
-    const float a = __builtin_amdgcn_exp2f(l.n * lg);
-    const float l1 = __builtin_amdgcn_logf(1.0f + a);
-    const float sqrt_se = __builtin_amdgcn_exp2f(half_m * l1);
-    const float op = __builtin_amdgcn_exp2f(l.m * (l.n * lg - l1));
-    const float t = 1.0f - op;
-    float k2 = l.ksat * sqrt_se * (t * t);
-    k2 = (fabsf(h2) < 0.1f || h2 < 0.0f) ? k_sat1 : k2;
+    if (sizeof(R) == 4) h2 = (i + 1 >= nint) ? h_f : h_i + R(i + 1) * dh;
+    const R lg = lg2(l.alpha * h2);
+    const R a = ex2(l.n * lg);
+    const R l1 = lg2(R(1.0) + a);
+    const R sqrt_se = ex2(half_m * l1);
+    const R op = ex2(l.m * (l.n * lg - l1));
+    const R t = R(1.0) - op;
+    R k2 = l.ksat * sqrt_se * (t * t);
+    k2 = (ab(h2) < R(0.1) || h2 < R(0.0)) ? k_sat1 : k2;
     g = g + ((k1 + k2) * hdh);
     k1 = k2;
+    if (sizeof(R) != 4) h2 = h2 + dh;
   }
-  return fabsf(g / l.ksat);
+  return ab(g / l.ksat);
 }
+template <> __device__ __forceinline__ float geff<float>(const LayerK<float> &l, float t1, float t2, int nint) {
+  return geff_fused<float>(l, t1, t2, nint);
+}
+#ifndef LGAR_LITERAL_GEFF_F64
+template <> __device__ __forceinline__ double geff<double>(const LayerK<double> &l, double t1, double t2, int nint) {
+  return geff_fused<double>(l, t1, t2, nint);
+}
+#endif
 #endif
 // calc_aet, models/physics/lgar/aet.py:17-51 (0.75: GlobalParams.py:75; clamp upper bound = PET rate)
 template <typename S> __device__ __forceinline__ S aet_fn(const LayerK<S> &l, S pet, real_t<S> dt_h, S psi, real_t<S> wp_psi) {
