@@ -29,7 +29,8 @@ extern "C" {
 #endif
 
 #define LGAR_FMAX 12  /* front slots per column (reference lists are unbounded, observed <= 8; overflow -> status bit) */
-#define LGAR_LMAX 3   /* soil layers compiled in (BASELINE configs: 3) */
+#define LGAR_LMIN 2   /* the reference itself needs >= 2 layers (Layer.py:204) */
+#define LGAR_LMAX 4   /* soil layers: kernels are compiled for 2, 3 and 4 (BASELINE configs: 3) */
 #define LGAR_GMAX 8   /* GIUH ordinates */
 #define LGAR_NSCAL (3 + LGAR_GMAX) /* scalars row count: ponded_water, previous_precip, ending_volume, giuh_queue[GMAX] */
 #define LGAR_NACC 10  /* precip, PET, AET, infiltration, runoff, percolation, giuh_runoff, discharge, ponded_water, ending_volume */
@@ -56,7 +57,7 @@ extern "C" {
 /* Run-time constants: the cfg keys dpLGAR(cfg) reads (models/dpLGAR.py:31-95, physics/GlobalParams.py:79-138). */
 typedef struct {
   int32_t n_columns;      /* N */
-  int32_t n_layers;       /* len(cfg.data.layer_thickness); must be LGAR_LMAX */
+  int32_t n_layers;       /* len(cfg.data.layer_thickness); LGAR_LMIN..LGAR_LMAX */
   int32_t n_steps;        /* T forcing rows processed by this call */
   int32_t num_subcycles;  /* cfg.models.num_subcycles */
   int32_t nint;           /* cfg.constants.nint (120) */

@@ -8,7 +8,7 @@ import os
 
 from . import build as _build
 
-FMAX, LMAX, GMAX = 12, 3, 8
+FMAX, LMIN, LMAX, GMAX = 12, 2, 4, 8
 NSCAL = 3 + GMAX
 NACC = 10
 F32, F64 = 0, 1

@@ -26,15 +26,28 @@ def _stale():
 
 
 def build(force=False, verbose=False):
-    """Compile csrc/*.hip -> csrc/liblgar_hip.so.  hipcc cross-compiles gfx950 without a GPU."""
+    """Compile csrc/*.hip -> csrc/liblgar_hip.so.  hipcc cross-compiles gfx950 without a GPU.  The translation units
+    are compiled concurrently (each instantiates the column physics for 2-4 layers x fp32/fp64) and then linked."""
     if not force and not _stale():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build liblgar_hip.so")
     srcs = [os.path.join(CSRC, f) for f in SOURCES if os.path.exists(os.path.join(CSRC, f))]
-    cmd = [hipcc] + FLAGS + srcs + ["-o", LIB]
+    cflags = [f for f in FLAGS if f != "-shared"]
+    objs, procs = [], []
+    for src in srcs:
+        obj = src[:-4] + ".o"
+        cmd = [hipcc] + cflags + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd)))
+        objs.append(obj)
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB]
     if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+        print(" ".join(link))
+    subprocess.check_call(link)
     return LIB

@@ -24,7 +24,7 @@ template <typename R> inline Glob<R> make_glob(const LgarDims *d) {
 
 inline int check_dims(const LgarDims *d) {
   if (!d) return LGAR_E_ARG;
-  if (d->n_columns <= 0 || d->n_layers != LGAR_LMAX) return LGAR_E_ARG;
+  if (d->n_columns <= 0 || d->n_layers < LGAR_LMIN || d->n_layers > LGAR_LMAX) return LGAR_E_ARG;
   if (d->n_giuh < 0 || d->n_giuh > LGAR_GMAX) return LGAR_E_ARG;
   if (d->nint <= 0 || d->num_subcycles <= 0 || d->n_steps < 0) return LGAR_E_ARG;
   if (!(d->dt_h > 0.0)) return LGAR_E_ARG;

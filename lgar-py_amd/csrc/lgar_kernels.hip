@@ -224,6 +224,28 @@ static KArgs<R> make_args(const LgarDims *d, const LgarParams *p, LgarState *s, 
 
 using namespace lgar;
 
+template <typename R, int NL>
+static void launch_init(const LgarDims *dims, const LgarParams *params, LgarState *state, int32_t *status, hipStream_t st) {
+  const unsigned grid = (unsigned)((dims->n_columns + WAVE - 1) / WAVE);
+  KArgs<R> a = make_args<R>(dims, params, state, nullptr, nullptr, status);
+  hipLaunchKernelGGL((lgar_init_kernel<R, NL, LGAR_FMAX>), dim3(grid), dim3(WAVE), 0, st, a);
+}
+template <typename R, int NL>
+static void launch_forward(const LgarDims *dims, const LgarParams *params, LgarState *state, const LgarForcing *forcing,
+                           const LgarStepOut *out, int32_t *status, hipStream_t st) {
+  const unsigned grid = (unsigned)((dims->n_columns + WAVE - 1) / WAVE);
+  KArgs<R> a = make_args<R>(dims, params, state, forcing, out, status);
+  hipLaunchKernelGGL((lgar_forward_kernel<R, NL, LGAR_FMAX>), dim3(grid), dim3(WAVE), 0, st, a);
+}
+
+#define LGAR_BY_LAYERS(R, FN, ...)                 \
+  switch (dims->n_layers) {                        \
+    case 2: FN<R, 2>(__VA_ARGS__); break;          \
+    case 3: FN<R, 3>(__VA_ARGS__); break;          \
+    case 4: FN<R, 4>(__VA_ARGS__); break;          \
+    default: return LGAR_E_ARG;                    \
+  }
+
 extern "C" {
 
 const char *lgar_version(void) { return "lgar-hip 0.1 (gfx950)"; }
@@ -236,14 +258,11 @@ int32_t lgar_state_init(const LgarDims *dims, const LgarParams *params, LgarStat
   if (rc) return rc;
   rc = check_state(params, state, status);
   if (rc) return rc;
-  const unsigned grid = (unsigned)((dims->n_columns + WAVE - 1) / WAVE);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == LGAR_F64) {
-    KArgs<double> a = make_args<double>(dims, params, state, nullptr, nullptr, status);
-    hipLaunchKernelGGL((lgar_init_kernel<double, LGAR_LMAX, LGAR_FMAX>), dim3(grid), dim3(WAVE), 0, st, a);
+    LGAR_BY_LAYERS(double, launch_init, dims, params, state, status, st)
   } else if (dtype == LGAR_F32) {
-    KArgs<float> a = make_args<float>(dims, params, state, nullptr, nullptr, status);
-    hipLaunchKernelGGL((lgar_init_kernel<float, LGAR_LMAX, LGAR_FMAX>), dim3(grid), dim3(WAVE), 0, st, a);
+    LGAR_BY_LAYERS(float, launch_init, dims, params, state, status, st)
   } else {
     return LGAR_E_ARG;
   }
@@ -258,14 +277,11 @@ int32_t lgar_forward(const LgarDims *dims, const LgarParams *params, LgarState *
   if (rc) return rc;
   if (dims->n_steps == 0) return 0;  // empty run: nothing to read
   if (!forcing || !forcing->precip || !forcing->pet) return LGAR_E_ARG;
-  const unsigned grid = (unsigned)((dims->n_columns + WAVE - 1) / WAVE);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == LGAR_F64) {
-    KArgs<double> a = make_args<double>(dims, params, state, forcing, out, status);
-    hipLaunchKernelGGL((lgar_forward_kernel<double, LGAR_LMAX, LGAR_FMAX>), dim3(grid), dim3(WAVE), 0, st, a);
+    LGAR_BY_LAYERS(double, launch_forward, dims, params, state, forcing, out, status, st)
   } else if (dtype == LGAR_F32) {
-    KArgs<float> a = make_args<float>(dims, params, state, forcing, out, status);
-    hipLaunchKernelGGL((lgar_forward_kernel<float, LGAR_LMAX, LGAR_FMAX>), dim3(grid), dim3(WAVE), 0, st, a);
+    LGAR_BY_LAYERS(float, launch_forward, dims, params, state, forcing, out, status, st)
   } else {
     return LGAR_E_ARG;
   }

@@ -75,6 +75,19 @@ template <typename R, int NL, int FMAX> __global__ __launch_bounds__(WAVE) void 
 
 using namespace lgar;
 
+template <typename R, int NL>
+static void launch_tangent(const LgarDims *dims, const LgarParams *params, const LgarParams *direction,
+                           const LgarForcing *forcing, const void *w_runoff, const void *w_perc, void *grad_out,
+                           void *tangent_runoff, int32_t *status, hipStream_t st) {
+  const unsigned grid = (unsigned)((dims->n_columns + WAVE - 1) / WAVE);
+  TArgs<R> a{dims->n_columns, dims->n_steps, (const R *)params->alpha, (const R *)params->n, (const R *)params->ksat,
+             (const R *)params->theta_e, (const R *)params->theta_r, (const R *)params->thickness,
+             (const R *)direction->alpha, (const R *)direction->n, (const R *)direction->ksat,
+             (const R *)forcing->precip, (const R *)forcing->pet, (const R *)w_runoff, (const R *)w_perc,
+             (R *)grad_out, (R *)tangent_runoff, status, make_glob<R>(dims)};
+  hipLaunchKernelGGL((lgar_tangent_kernel<R, NL, TANGENT_FMAX>), dim3(grid), dim3(WAVE), 0, st, a);
+}
+
 extern "C" int32_t lgar_forward_tangent(const LgarDims *dims, const LgarParams *params, const LgarParams *direction,
                                         const LgarForcing *forcing, const void *w_runoff, const void *w_perc,
                                         void *grad_out, void *tangent_runoff, int32_t *status, int32_t dtype,
@@ -85,24 +98,21 @@ extern "C" int32_t lgar_forward_tangent(const LgarDims *dims, const LgarParams *
   if (!params->alpha || !params->n || !params->ksat || !params->theta_e || !params->theta_r || !params->thickness)
     return LGAR_E_ARG;
   if (dims->n_steps > 0 && (!forcing->precip || !forcing->pet)) return LGAR_E_ARG;
-  const unsigned grid = (unsigned)((dims->n_columns + WAVE - 1) / WAVE);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == LGAR_F64) {
-    typedef double R;
-    TArgs<R> a{dims->n_columns, dims->n_steps, (const R *)params->alpha, (const R *)params->n, (const R *)params->ksat,
-               (const R *)params->theta_e, (const R *)params->theta_r, (const R *)params->thickness,
-               (const R *)direction->alpha, (const R *)direction->n, (const R *)direction->ksat,
-               (const R *)forcing->precip, (const R *)forcing->pet, (const R *)w_runoff, (const R *)w_perc,
-               (R *)grad_out, (R *)tangent_runoff, status, make_glob<R>(dims)};
-    hipLaunchKernelGGL((lgar_tangent_kernel<R, LGAR_LMAX, TANGENT_FMAX>), dim3(grid), dim3(WAVE), 0, st, a);
+    switch (dims->n_layers) {
+      case 2: launch_tangent<double, 2>(dims, params, direction, forcing, w_runoff, w_perc, grad_out, tangent_runoff, status, st); break;
+      case 3: launch_tangent<double, 3>(dims, params, direction, forcing, w_runoff, w_perc, grad_out, tangent_runoff, status, st); break;
+      case 4: launch_tangent<double, 4>(dims, params, direction, forcing, w_runoff, w_perc, grad_out, tangent_runoff, status, st); break;
+      default: return LGAR_E_ARG;
+    }
   } else if (dtype == LGAR_F32) {
-    typedef float R;
-    TArgs<R> a{dims->n_columns, dims->n_steps, (const R *)params->alpha, (const R *)params->n, (const R *)params->ksat,
-               (const R *)params->theta_e, (const R *)params->theta_r, (const R *)params->thickness,
-               (const R *)direction->alpha, (const R *)direction->n, (const R *)direction->ksat,
-               (const R *)forcing->precip, (const R *)forcing->pet, (const R *)w_runoff, (const R *)w_perc,
-               (R *)grad_out, (R *)tangent_runoff, status, make_glob<R>(dims)};
-    hipLaunchKernelGGL((lgar_tangent_kernel<R, LGAR_LMAX, TANGENT_FMAX>), dim3(grid), dim3(WAVE), 0, st, a);
+    switch (dims->n_layers) {
+      case 2: launch_tangent<float, 2>(dims, params, direction, forcing, w_runoff, w_perc, grad_out, tangent_runoff, status, st); break;
+      case 3: launch_tangent<float, 3>(dims, params, direction, forcing, w_runoff, w_perc, grad_out, tangent_runoff, status, st); break;
+      case 4: launch_tangent<float, 4>(dims, params, direction, forcing, w_runoff, w_perc, grad_out, tangent_runoff, status, st); break;
+      default: return LGAR_E_ARG;
+    }
   } else {
     return LGAR_E_ARG;
   }

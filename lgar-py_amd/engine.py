@@ -9,7 +9,7 @@ import ctypes as C
 import torch
 
 from . import _capi
-from ._capi import ACC_NAMES, FMAX, GMAX, LMAX, NACC, NSCAL, LgarError
+from ._capi import ACC_NAMES, FMAX, GMAX, LMAX, LMIN, NACC, NSCAL, LgarError
 
 
 def _require_gpu(device):
@@ -52,8 +52,8 @@ class LgarEngine:
         self.alpha, self.n, self.ksat = prep(alpha), prep(n), prep(ksat)
         self.theta_e, self.theta_r, self.thickness = prep(theta_e), prep(theta_r), prep(thickness)
         L, N = self.alpha.shape
-        if L != LMAX:
-            raise LgarError("this build supports exactly %d soil layers (got %d)" % (LMAX, L))
+        if not LMIN <= L <= LMAX:
+            raise LgarError("this build supports %d..%d soil layers (got %d)" % (LMIN, LMAX, L))
         for t in (self.n, self.ksat, self.theta_e, self.theta_r, self.thickness):
             if tuple(t.shape) != (L, N):
                 raise LgarError("parameter shapes differ: expected %s, got %s" % ((L, N), tuple(t.shape)))

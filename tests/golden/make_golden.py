@@ -330,6 +330,16 @@ CASES = {
     "grad_synth0_12h": (run_case, dict(forcing="forcing_data_synth_0.csv", soil=PHIL, pdm=0.0, subcycle_s=3600, forcing_res_s=3600, endtime_h=12.0, grad=True)),
     "grad_synth1_phil": (run_case, dict(forcing="forcing_data_synth_1.txt", soil=PHIL, pdm=0.0, subcycle_s=300, forcing_res_s=300, endtime_h=12.0, grad=True)),
 }
+# other layer counts (the reference builds one Layer object per entry of cfg.data.layer_thickness, Layer.py:77-89)
+TWO = dict(alpha=[0.01, 0.0083272], n=[1.66, 1.299], ksat=[0.756, 0.07], theta_e=[0.44, 0.4773], theta_r=[0.07, 0.0831],
+           thickness=[60.0, 140.0])
+FOUR = dict(alpha=[0.0031297, 0.01, 0.0083272, 0.0037454], n=[1.6858, 1.47, 1.299, 1.6151], ksat=[0.45, 0.504, 0.07, 0.45],
+            theta_e=[0.4513, 0.40, 0.4773, 0.4617], theta_r=[0.0648, 0.06, 0.0831, 0.0668], thickness=[30.0, 40.0, 90.0, 40.0])
+CASES["two_layer_synth1"] = (run_case, dict(forcing="forcing_data_synth_1.txt", soil=TWO, pdm=0.0, subcycle_s=300, forcing_res_s=300, endtime_h=12.0))
+CASES["two_layer_phil_600"] = (run_case, dict(forcing=PH, soil=TWO, pdm=1.0, subcycle_s=3600, forcing_res_s=3600, endtime_h=600.0))
+CASES["four_layer_synth1"] = (run_case, dict(forcing="forcing_data_synth_1.txt", soil=FOUR, pdm=0.0, subcycle_s=300, forcing_res_s=300, endtime_h=12.0))
+CASES["four_layer_phil_600"] = (run_case, dict(forcing=PH, soil=FOUR, pdm=2, subcycle_s=3600, forcing_res_s=3600, endtime_h=600.0))
+CASES["four_layer_synth0_600"] = (run_case, dict(forcing="forcing_data_synth_0.csv", soil=FOUR, pdm=0.0, subcycle_s=3600, forcing_res_s=3600, endtime_h=600.0))
 # perturbed-parameter ensembles: the roofline/ensemble configs use ±10 % columns
 for s in range(8):
     rng = np.random.default_rng(1000 + s)

@@ -237,7 +237,7 @@ def test_bad_arguments_are_rejected():
     import lgar_py_amd as lg
     from lgar_py_amd import _capi
     with pytest.raises(lg.LgarError):
-        lg.LgarEngine([1e-2] * 2, [1.5] * 2, [1.0] * 2, [0.4] * 2, [0.1] * 2, [10.0] * 2, n_columns=4)  # 2 layers
+        lg.LgarEngine([1e-2] * 5, [1.5] * 5, [1.0] * 5, [0.4] * 5, [0.1] * 5, [10.0] * 5, n_columns=4)  # 5 layers: not compiled in
     g = np.load(os.path.join(GOLDEN, "synth1_phil.npz"))
     eng = _engine(g, 4, torch.float64)
     with pytest.raises(lg.LgarError):
