@@ -183,28 +183,29 @@ __device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x)
 __device__ __forceinline__ double lg2(double x) { return log2(x); }
 __device__ __forceinline__ double ex2(double x) { return exp2(x); }
 
-template <typename R> __device__ __forceinline__ R geff_fused(const LayerK<R> &l, R theta1, R theta2, int nint) {
-  const R se_i = se_from_theta(l, theta1);
-  const R se_f = se_from_theta(l, theta2);
-  const R h_i = h_from_se(l, se_i);
-  const R h_f = h_from_se(l, se_f);
-  const R dh = (h_f - h_i) / R(nint);
-  const R hdh = dh / R(2.0);
-  const R k_sat1 = k_from_se(l, R(1.0));  // K at Se == 1 (|h| < 0.1)
-  const R half_m = R(-0.5) * l.m;
-  R g = R(0.0);
-  R k1 = k_from_se(l, se_i);
-  R h2 = h_i + dh;
+template <typename S> __device__ __forceinline__ S geff_fused(const LayerK<S> &l, S theta1, S theta2, int nint) {
+  using R = real_t<S>;
+  const S se_i = se_from_theta(l, theta1);
+  const S se_f = se_from_theta(l, theta2);
+  const S h_i = h_from_se(l, se_i);
+  const S h_f = h_from_se(l, se_f);
+  const S dh = (h_f - h_i) / R(nint);
+  const S hdh = dh / R(2.0);
+  const S k_sat1 = k_from_se(l, S(R(1.0)));  // K at Se == 1 (|h| < 0.1)
+  const S half_m = R(-0.5) * l.m;
+  S g = S(R(0.0));
+  S k1 = k_from_se(l, se_i);
+  S h2 = h_i + dh;
   for (int i = 0; i < nint; i++) {
     if (sizeof(R) == 4) h2 = (i + 1 >= nint) ? h_f : h_i + R(i + 1) * dh;
-    const R lg = lg2(l.alpha * h2);
-    const R a = ex2(l.n * lg);
-    const R l1 = lg2(R(1.0) + a);
-    const R sqrt_se = ex2(half_m * l1);
-    const R op = ex2(l.m * (l.n * lg - l1));
-    const R t = R(1.0) - op;
-    R k2 = l.ksat * sqrt_se * (t * t);
-    k2 = (ab(h2) < R(0.1) || h2 < R(0.0)) ? k_sat1 : k2;
+    const S lg = lg2(l.alpha * h2);
+    const S a = ex2(l.n * lg);
+    const S l1 = lg2(R(1.0) + a);
+    const S sqrt_se = ex2(half_m * l1);
+    const S op = ex2(l.m * (l.n * lg - l1));
+    const S t = R(1.0) - op;
+    S k2 = l.ksat * sqrt_se * (t * t);
+    k2 = (ab(val(h2)) < R(0.1) || val(h2) < R(0.0)) ? k_sat1 : k2;
     g = g + ((k1 + k2) * hdh);
     k1 = k2;
     if (sizeof(R) != 4) h2 = h2 + dh;

@@ -63,4 +63,23 @@ template <typename R> __device__ __forceinline__ Dual<R> mn(const Dual<R> &a, co
   return Dual<R>(a.v, R(0.5) * (a.d + b.d));
 }
 
+// log2 / exp2 (the fused Geff node, lgar_device.hpp): d log2 x = dx / (x ln 2), d 2^y = 2^y ln 2 dy
+template <typename R> __device__ __forceinline__ Dual<R> lg2(const Dual<R> &x) {
+  return Dual<R>(lg2(x.v), (x.v > R(0)) ? x.d / (x.v * R(0.6931471805599453)) : R(0));
+}
+template <typename R> __device__ __forceinline__ Dual<R> ex2(const Dual<R> &y) {
+  const R v = ex2(y.v);
+  return Dual<R>(v, v * R(0.6931471805599453) * y.d);
+}
+#ifndef LGAR_NO_FUSED_GEFF
+template <> __device__ __forceinline__ Dual<double> geff<Dual<double>>(const LayerK<Dual<double>> &l, Dual<double> t1,
+                                                                       Dual<double> t2, int nint) {
+  return geff_fused<Dual<double>>(l, t1, t2, nint);
+}
+template <> __device__ __forceinline__ Dual<float> geff<Dual<float>>(const LayerK<Dual<float>> &l, Dual<float> t1,
+                                                                     Dual<float> t2, int nint) {
+  return geff_fused<Dual<float>>(l, t1, t2, nint);
+}
+#endif
+
 }  // namespace lgar
