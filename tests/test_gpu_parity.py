@@ -251,3 +251,61 @@ def test_bad_arguments_are_rejected():
     # empty run is a no-op
     out = eng.forward(torch.zeros(0, 4), torch.zeros(0, 4))
     assert out["runoff"].shape == (0, 4)
+
+
+def test_heterogeneous_hourly_with_pet_vs_oracle_fp64():
+    """Perturbed columns under the hourly Phillipsburg forcing (rain + PET: AET, dry-over-wet, merges, base case)
+    scaled per column: kernel (literal searches) vs oracle column by column, 600 steps."""
+    import lgar_py_amd as lg
+    from lgar_py_amd import workloads as W
+    from oracle import lgar_oracle as O
+    g = np.load(os.path.join(GOLDEN, "phil_hourly_3000.npz"))
+    N, T = 256, 600
+    P = W.perturbed_columns(N, seed=21)
+    sc = W.forcing_scale(N, 0.5, 2.0, seed=22)
+    pr = g["forcing"][:T, 0:1] * sc[None, :]
+    pe = g["forcing"][:T, 1:2] * np.ones((1, N))
+    ro, pc, acc, st = O.run_columns(P["alpha"], P["n"], P["ksat"], P["theta_e"], P["theta_r"], P["thickness"], pr, pe,
+                                    pdm=2.0, dt_h=1.0)
+    for mode, tol in ((0, 1e-6), (1, 1e-6)):
+        eng = lg.LgarEngine(P["alpha"], P["n"], P["ksat"], P["theta_e"], P["theta_r"], P["thickness"], dt_h=1.0,
+                            ponded_depth_max=2.0, dtype=torch.float64, search_mode=mode)
+        out = eng.forward(torch.tensor(pr), torch.tensor(pe), series=("runoff", "AET", "infiltration"), check=False)
+        gst = eng.status.cpu().numpy()
+        if mode == 0:
+            assert ((st != 0) == (gst != 0)).all()
+        ok = (st == 0) & (gst == 0)
+        assert ok.mean() > 0.9
+        tot = eng.totals.cpu().numpy()
+        assert _rel(tot[:8, ok], acc[:8, ok], 1e-3).max() <= tol, mode
+        assert _rel(tot[9, ok], acc[9, ok]).max() <= tol
+        assert tot[2, ok].min() > 0  # AET path exercised
+        fr = eng.fronts()
+        assert fr["n_fronts"][ok].max() <= 12
+
+
+def test_wide_parameter_ensemble_vs_oracle_fp64():
+    """BASELINE configs[4]'s parameter ranges (alpha in [0.0015, 0.015], n in [1.1, 3], Ksat in [0.01, 5]) under the
+    synth_1 storm: kernel vs oracle per column; the same columns leave the reference's domain of validity."""
+    import lgar_py_amd as lg
+    from lgar_py_amd import workloads as W
+    from oracle import lgar_oracle as O
+    N = 512
+    E = W.ensemble_columns(N, seed=3)
+    f = W.synth1_forcing()
+    pr = np.repeat(f[:, 0:1], N, 1)
+    pe = np.zeros_like(pr)
+    ro, pc, acc, st = O.run_columns(E["alpha"], E["n"], E["ksat"], E["theta_e"], E["theta_r"], E["thickness"], pr, pe,
+                                    pdm=0.0, dt_h=300.0 / 3600.0)
+    eng = lg.LgarEngine(E["alpha"], E["n"], E["ksat"], E["theta_e"], E["theta_r"], E["thickness"], dt_h=300.0 / 3600.0,
+                        ponded_depth_max=0.0, dtype=torch.float64, search_mode=0)
+    out = eng.forward(torch.tensor(pr), torch.tensor(pe), series=("runoff",), check=False)
+    gst = eng.status.cpu().numpy()
+    agree = ((st != 0) == (gst != 0))
+    assert agree.mean() >= 0.995  # a borderline column may flip on a 1-ulp pow difference
+    ok = (st == 0) & (gst == 0)
+    assert ok.mean() > 0.5
+    tot = eng.totals.cpu().numpy()
+    assert _rel(tot[:8, ok], acc[:8, ok], 1e-3).max() <= 1e-6
+    got = out["runoff"].cpu().numpy()
+    assert np.abs(got[:, ok] - ro[:, ok]).max() <= 1e-6 * max(1.0, np.abs(ro[:, ok]).max())
