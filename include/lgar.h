@@ -63,7 +63,10 @@ typedef struct {
   int32_t nint;           /* cfg.constants.nint (120) */
   int32_t n_giuh;         /* len(cfg.data.giuh_ordinates) <= LGAR_GMAX */
   int32_t search_mode;    /* 0 = the reference's literal line searches (Layer.py:275-317, 681-701) */
-  int32_t reserved;
+  int32_t bottom_mode;    /* 0 = reference behaviour: a front reaching the domain bottom sets LGAR_ST_BOTTOM and the
+                             column stops (the reference crashes, Layer.py:980); 1 = LGAR-C intent: the bottom layer is
+                             exempt from the layer-boundary step and wetting_front_cross_domain_boundary
+                             (Layer.py:1010-1053) turns the overshoot into percolation.  Parity of mode 1 is unpinned. */
   double dt_h;               /* cfg.models.subcycle_length_h */
   double initial_psi;        /* cfg.data.initial_psi */
   double ponded_depth_max;   /* cfg.data.ponded_depth_max */

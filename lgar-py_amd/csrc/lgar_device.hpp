@@ -300,7 +300,7 @@ template <typename S> __device__ __forceinline__ S aet_fn(const LayerK<S> &l, S 
 template <typename R> struct Glob {
   R dt_h, initial_psi, pdm, wp_psi, frozen;
   R giuh[LGAR_GMAX];
-  int nint, nsub, ng, search_mode;
+  int nint, nsub, ng, search_mode, bottom_mode;
   long long iter_cap;
 };
 
@@ -699,7 +699,11 @@ template <typename S, int NL, int FMAX> struct Column {
       const int nx = i + 1, nn = i + 2;
       const S cumk = cum_at(k);
       if (!(val(F.Z(i)) > val(cumk) && val(F.Z(nx)) == val(cumk))) { i++; continue; }
-      if (k == NL - 1) { status |= LGAR_ST_BOTTOM; return; }  // reference: AttributeError at Layer.py:980
+      if (k == NL - 1) {
+        if (G.bottom_mode == 0) { status |= LGAR_ST_BOTTOM; return; }  // reference: AttributeError at Layer.py:980
+        i++;  // LGAR-C intent: the bottom layer has no layer below; the domain-boundary step handles this front
+        continue;
+      }
       if (nn >= nf) { status |= LGAR_ST_STRUCT; return; }
       const LayerK<S> lk = pick(P, k);
       const LayerK<S> ln = pick(P, k + 1);
@@ -720,6 +724,26 @@ template <typename S, int NL, int FMAX> struct Column {
       F.set_flag(nx, k + 1, false);
       i += 2;
     }
+  }
+
+  // wetting_front_cross_domain_boundary, Layer.py:1010-1053 (bottom_mode 1 only; the reference cannot reach it without
+  // crashing): the second-to-last front of the domain has passed the column bottom -> its overshoot leaves as
+  // percolation, the bottom front takes its theta, and it is deleted.
+  __device__ __forceinline__ S cross_domain_boundary() {
+    S flux = S(R(0.0));
+    if (nf < 2) return flux;
+    const int i = nf - 2, nx = nf - 1;
+    const int k = F.layer(i);
+    if (val(F.Z(i)) > val(cum_at(k))) {
+      const LayerK<S> lk = pick(P, k);
+      flux = (F.TH(i) - F.TH(nx)) * (F.Z(i) - F.Z(nx));
+      F.TH(nx) = F.TH(i);
+      S se = se_from_theta(lk, F.TH(i));
+      F.PS(nx) = h_from_se(lk, se);
+      k_deepest = k_from_se(lk, se);
+      fdel(i);
+    }
+    return flux;
   }
 
   // fix_dry_over_wet_fronts / cleanup_wetting_fronts / update_layer_fronts, Layer.py:1055-1143: per layer,
@@ -792,6 +816,7 @@ template <typename S, int NL, int FMAX> struct Column {
       if (pass == 0) cross_layer_boundary();
     }
     S bottom_flux = S(R(0.0));
+    if (G.bottom_mode != 0) bottom_flux = cross_domain_boundary();
     S mass_change = fix_dry_over_wet();
     if (ab(val(mass_change)) > R(1e-7)) aet = aet - mass_change;
     update_psi();
@@ -881,13 +906,15 @@ template <typename S, int NL, int FMAX> struct Column {
     int lo, len;
     range_of(kfp, lo, len);
     const int nxt_i = lo + 1;  // the front after the FIRST front of the free-drainage front's layer (quirk)
-    if (nxt_i >= nf) { status |= LGAR_ST_STRUCT; return; }
+    // reference: AttributeError (Layer.py:1606) when the free-drainage front is the lone front of the bottom layer.
+    // With one front per layer no neighbour is needed (Geff = 0); bottom_mode 1 lets that case through.
+    if (nxt_i >= nf && (nf != NL || G.bottom_mode == 0)) { status |= LGAR_ST_STRUCT; return; }
     const LayerK<S> lk = pick(P, kfp);
     S g = S(R(0.0));
     // quirk: with a fully saturated one-front top layer right after a layer crossing, nxt_i is a front of the
     // NEXT layer and Se > 1: the reference raises ValueError (negative pow base, physics/utils.py:25-27);
     // here the NaN is flagged and the IEEE min below drops it (all ponded water infiltrates).
-    if (nf != NL) g = geff(lk, F.TH(nxt_i), lk.te, G.nint);
+    if (nf != NL) g = geff(lk, F.TH(nxt_i < nf ? nxt_i : nf - 1), lk.te, G.nint);
     if (is_nan(val(g))) status |= LGAR_ST_NAN | LGAR_ST_NEGBASE;
     S f_p;
     if (kfp == 0) {

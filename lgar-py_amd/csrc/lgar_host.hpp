@@ -18,6 +18,7 @@ template <typename R> inline Glob<R> make_glob(const LgarDims *d) {
   G.nsub = d->num_subcycles;
   G.ng = d->n_giuh;
   G.search_mode = d->search_mode;
+  G.bottom_mode = d->bottom_mode;
   G.iter_cap = d->iter_cap > 0 ? d->iter_cap : 2000000LL;
   return G;
 }

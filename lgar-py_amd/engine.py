@@ -27,12 +27,14 @@ class LgarEngine:
     Parameters are [L] (shared by all columns) or [L, N] tensors/sequences; forcing is [T, N] (cm/h).
     search_mode: 1 (default) = bracketed-Newton psi search + closed-form jumps in the depth search (same roots, same
     tolerances); 0 = the reference's literal fixed-step line searches (Layer.py:275-317, 681-701).
+    bottom_mode: 0 (default) = like the reference, a front reaching the domain bottom faults the column; 1 = it leaves
+    the column as percolation (LGAR-C intent; parity unpinned, the reference crashes there).
     """
 
     def __init__(self, alpha, n, ksat, theta_e, theta_r, thickness, *, n_columns=None, dt_h=1.0, num_subcycles=1,
                  initial_psi=2000.0, ponded_depth_max=0.0, wilting_point_psi=15495.0, frozen_factor=1.0, nint=120,
                  giuh_ordinates=(0.06, 0.51, 0.28, 0.12, 0.03), dtype=torch.float64, device="cuda:0",
-                 iter_cap=0, search_mode=1):
+                 iter_cap=0, search_mode=1, bottom_mode=0):
         self.device = torch.device(device)
         _require_gpu(self.device)
         self.lib = _capi.load()
@@ -69,6 +71,7 @@ class LgarEngine:
         for i, g in enumerate(giuh_ordinates):
             d.giuh[i] = float(g)
         d.iter_cap = int(iter_cap)
+        d.bottom_mode = int(bottom_mode)
 
         z = lambda *shape, dt=dtype: torch.zeros(*shape, dtype=dt, device=self.device)
         self.depth, self.theta, self.psi = z(FMAX, N), z(FMAX, N), z(FMAX, N)

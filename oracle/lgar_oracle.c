@@ -154,7 +154,7 @@ static double geff_k(const lgo_params *p, lgo_state *s, int k, double t1, double
 
 /* Layer.mass_balance, layers/Layer.py:795-824.  Layer sums are combined s0 + (s1 + (s2 + ...)). */
 double lgo_mass_balance(const lgo_params *p, const lgo_state *s) {
-  double ls[LGO_LMAX];
+  double ls[LGO_LMAX] = {0};
   for (int k = 0; k < p->L; k++) ls[k] = 0.0;
   int i = 0;
   for (int k = 0; k < p->L; k++) {
@@ -450,7 +450,10 @@ static void cross_layer_boundary(const lgo_params *p, lgo_state *s) {
       if (nx >= s->nf) { *st |= LGO_ST_STRUCT; break; }
       lgo_front *c = &s->f[i], *n = &s->f[nx];
       if (c->depth > p->cum[k] && n->depth == p->cum[k]) {
-        if (k == p->L - 1) { *st |= LGO_ST_BOTTOM; return; } /* reference: AttributeError at Layer.py:980 */
+        if (k == p->L - 1) {
+          if (p->bottom_mode == 0) { *st |= LGO_ST_BOTTOM; return; } /* reference: AttributeError at Layer.py:980 */
+          continue; /* LGAR-C intent: the domain-boundary step handles this front */
+        }
         if (nn >= s->nf) { *st |= LGO_ST_STRUCT; return; }
         lgo_front *q = &s->f[nn];
         double overshot = c->depth - n->depth;
@@ -478,7 +481,7 @@ static void cross_layer_boundary(const lgo_params *p, lgo_state *s) {
 /* wetting_front_cross_domain_boundary, Layer.py:1010-1053 (unreachable in the reference without crashing first) */
 static double cross_domain_boundary(const lgo_params *p, lgo_state *s) {
   int *st = &s->status;
-  double ls[LGO_LMAX];
+  double ls[LGO_LMAX] = {0};
   for (int k = 0; k < p->L; k++) {
     int lo[LGO_LMAX], len[LGO_LMAX];
     ranges(p, s, lo, len);
@@ -497,7 +500,7 @@ static double cross_domain_boundary(const lgo_params *p, lgo_state *s) {
           n->psi = h_k(p, k, se, st);
           n->k = K_k(p, k, se, st);
           fdel(s, i);
-          *st |= LGO_ST_BOTTOM;
+          if (p->bottom_mode == 0) *st |= LGO_ST_BOTTOM;
         }
       }
       flux = flux + tmp;
@@ -512,7 +515,7 @@ static double cross_domain_boundary(const lgo_params *p, lgo_state *s) {
 /* fix_dry_over_wet_fronts / cleanup_wetting_fronts / update_layer_fronts, Layer.py:1055-1143 */
 static double fix_dry_over_wet(const lgo_params *p, lgo_state *s) {
   int *st = &s->status;
-  double ls[LGO_LMAX];
+  double ls[LGO_LMAX] = {0};
   for (int k = 0; k < p->L; k++) {
     int lo[LGO_LMAX], len[LGO_LMAX];
     ranges(p, s, lo, len);
@@ -682,7 +685,9 @@ static void insert_water(const lgo_params *p, lgo_state *s, int fdd, double prec
   /* get_drainage_neighbors(0): (first front of fdd's layer, fdd, the front after that FIRST front) */
   int cur_i = lo[kfp];
   int nxt_i = cur_i + 1;
-  if (nxt_i >= s->nf) { *st |= LGO_ST_STRUCT; return; } /* reference: AttributeError, Layer.py:1606 */
+  /* reference: AttributeError at Layer.py:1606 when the free-drainage front is the lone front of the bottom layer.
+   * With one front per layer no neighbour is needed (Geff = 0); bottom_mode 1 lets that case through. */
+  if (nxt_i >= s->nf && (s->nf != p->L || p->bottom_mode == 0)) { *st |= LGO_ST_STRUCT; return; }
   double geff;
   if (s->nf == p->L) geff = 0.0;
   else geff = geff_k(p, s, kfp, s->f[nxt_i].theta, p->theta_e[kfp]);
