@@ -48,6 +48,19 @@ def measured_traffic(N, T, dtype):
     return best
 
 
+def measured_valu(N, T, dtype):
+    """Compute-side roof from the committed PMC passes (profiles/*/traffic.json 'valu' block), same workload only."""
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    for r in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        f = os.path.join(pdir, r, "traffic.json")
+        if os.path.exists(f):
+            t = json.load(open(f))
+            if (t.get("columns"), t.get("timesteps"), t.get("dtype")) == (N, T, dtype) and "valu" in t:
+                best = t["valu"]
+    return best
+
+
 def cpu_baseline(target_s=12.0):
     """Oracle (C restatement, fp64, OpenMP over columns) timed on this host on a bounded sample of the
     same workload.  A reported baseline, never the thing measured above."""
@@ -204,6 +217,7 @@ def main():
                          "kernel_ms": kern_ms, "alg_bytes_per_column_timestep": b_alg,
                          "note": "path is VALU bound, not HBM bound (~1e3 flop/B; SQ_ACTIVE_INST_VALU ~97% of SIMD cycles in "
                                  "profiles/r01/bench_v4_pmc_summary.txt); see DESIGN.md"},
+            "valu_roofline": measured_valu(N, T, args.dtype),
             "faulted_columns": int(faulted.item()),
             "basin_runoff_total_cm": float(basin.sum().item()),
         }
