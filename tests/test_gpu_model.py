@@ -90,3 +90,29 @@ def test_batched_forward_and_ensemble(tmp_path):
         model.ksat[0].mul_(0.5)
     model.update_soil_parameters()
     assert abs(float(model.engine.ksat[0, 0]) - 0.225) < 1e-12
+
+
+def test_streamed_run_equals_single_shot():
+    """pipeline.run_streamed (double-buffered chunks on a side stream) == one launch over the whole [T, N] forcing."""
+    import lgar_py_amd as lg
+    from lgar_py_amd import workloads as W
+    from lgar_py_amd.pipeline import run_streamed
+    g = np.load(os.path.join(GOLDEN, "phil_hourly_3000.npz"))
+    N, T = 300, 700
+    P = W.perturbed_columns(N, seed=31)
+    sc = W.forcing_scale(N, 0.5, 1.5, seed=32)
+    kw = dict(dt_h=1.0, ponded_depth_max=2.0, dtype=torch.float64)
+    x = g["forcing"][:T]
+    a = lg.LgarEngine(P["alpha"], P["n"], P["ksat"], P["theta_e"], P["theta_r"], P["thickness"], **kw)
+    pr = torch.tensor(x[:, 0:1] * sc[None, :])
+    pe = torch.tensor(x[:, 1:2] * np.ones((1, N)))
+    full = a.forward(pr, pe, series=("runoff", "AET"), check=False)
+    b = lg.LgarEngine(P["alpha"], P["n"], P["ksat"], P["theta_e"], P["theta_r"], P["thickness"], **kw)
+    got = run_streamed(b, x, scale=sc, chunk=97, series=("runoff", "AET"), reduce_basin=False)
+    for nm in ("runoff", "AET"):
+        assert torch.equal(got[nm], full[nm]), nm
+    assert torch.equal(a.totals, b.totals) and torch.equal(a.theta, b.theta)
+    c = lg.LgarEngine(P["alpha"], P["n"], P["ksat"], P["theta_e"], P["theta_r"], P["thickness"], **kw)
+    basin = run_streamed(c, x, scale=sc, chunk=256, series=("runoff",))["runoff"]
+    assert basin.shape == (T,)
+    assert torch.allclose(basin, full["runoff"].sum(1), rtol=1e-12, atol=1e-12)
