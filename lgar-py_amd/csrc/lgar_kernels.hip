@@ -135,10 +135,18 @@ __global__ __launch_bounds__(WAVE, (sizeof(R) == 4) ? 3 : 1) void lgar_forward_k
 #pragma unroll
   for (int j = 0; j < 8; j++) tot[j] = a.totals[j * N + c];
 
+  // software prefetch: the next step's forcing is requested before this step is integrated, so its HBM latency
+  // hides under ~10^4 cycles of VALU work
+  R precip_nx = a.T > 0 ? a.precip[c] : R(0);
+  R pet_nx = a.T > 0 ? a.pet[c] : R(0);
   for (int t = 0; t < a.T; t++) {
     const size_t o = (size_t)t * N + c;
-    const R precip = a.precip[o];
-    const R pet = a.pet[o];
+    const R precip = precip_nx;
+    const R pet = pet_nx;
+    if (t + 1 < a.T) {
+      precip_nx = a.precip[o + N];
+      pet_nx = a.pet[o + N];
+    }
     col.forward(precip, pet);
     const R acc[LGAR_NACC] = {col.a_precip, col.a_pet, col.a_aet, col.a_infil, col.a_runoff,
                               col.a_perc, col.a_giuh, col.a_disch, col.ponded_water, col.ending_volume};
