@@ -67,7 +67,9 @@ def cpu_baseline(target_s=12.0):
     from lgar_py_amd import workloads as W
     from oracle import lgar_oracle as O
 
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # the GPU box gives one GPU a 16-core CPU share (more OpenMP threads than that only oversubscribe the cgroup)
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = int(os.environ.get("LGAR_CPU_THREADS", min(avail, 16)))
     f = W.synth1_forcing()
     T = f.shape[0]
 
