@@ -67,6 +67,9 @@ typedef struct {
                              column stops (the reference crashes, Layer.py:980); 1 = LGAR-C intent: the bottom layer is
                              exempt from the layer-boundary step and wetting_front_cross_domain_boundary
                              (Layer.py:1010-1053) turns the overshoot into percolation.  Parity of mode 1 is unpinned. */
+  int32_t use_closed_form_G; /* cfg.data.use_closed_form_G: Brooks-Corey closed-form capillary drive
+                                (lgar/green_ampt.py:85-98) instead of the nint-interval trapezoid (:45-84) */
+  int32_t reserved;
   double dt_h;               /* cfg.models.subcycle_length_h */
   double initial_psi;        /* cfg.data.initial_psi */
   double ponded_depth_max;   /* cfg.data.ponded_depth_max */

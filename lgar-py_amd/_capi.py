@@ -24,7 +24,7 @@ EXPORTS = ["lgar_version", "lgar_fmax", "lgar_lmax", "lgar_state_init", "lgar_fo
 class LgarDims(C.Structure):
     _fields_ = [("n_columns", C.c_int32), ("n_layers", C.c_int32), ("n_steps", C.c_int32),
                 ("num_subcycles", C.c_int32), ("nint", C.c_int32), ("n_giuh", C.c_int32),
-                ("search_mode", C.c_int32), ("bottom_mode", C.c_int32),
+                ("search_mode", C.c_int32), ("bottom_mode", C.c_int32), ("use_closed_form_G", C.c_int32), ("reserved", C.c_int32),
                 ("dt_h", C.c_double), ("initial_psi", C.c_double), ("ponded_depth_max", C.c_double),
                 ("wilting_point_psi", C.c_double), ("frozen_factor", C.c_double), ("giuh", C.c_double * GMAX),
                 ("iter_cap", C.c_int64)]

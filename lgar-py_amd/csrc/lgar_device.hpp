@@ -278,6 +278,26 @@ template <> __device__ __forceinline__ double geff<double>(const LayerK<double> 
 }
 #endif
 #endif
+// calc_geff with use_closed_form_G (lgar/green_ampt.py:85-98): Brooks-Corey estimate from the van Genuchten parameters
+// (calc_bc_lambda / calc_bc_psib, physics/utils.py:54-64, 84-99).  Operator precedence as written in the reference:
+// geff = h_c * Se_i^e - Se_f^e / (1 - Se_f^e), with Se_f from theta_1 and Se_i from theta_2; inf/nan -> h_c.
+template <typename S> __device__ __forceinline__ S geff_closed(const LayerK<S> &l, S theta1, S theta2) {
+  using R = real_t<S>;
+  const S p = R(1.0) + (R(2.0) / l.m);
+  const S lambda = R(2.0) / (p - R(3.0));
+  const S psib = (p + R(3.0)) * (R(147.8) + R(8.1) * p + R(0.092) * p * p) /
+                 (R(2.0) * l.alpha * p * (p - R(1.0)) * (R(55.6) + R(7.4) * p + p * p));
+  const S se_f = se_from_theta(l, theta1);
+  const S se_i = se_from_theta(l, theta2);
+  const S h_c = psib * (R(2.0) + R(3.0) * lambda) / (R(1.0) + R(3.0) * lambda);
+  const S e = R(3.0) + R(1.0) / lambda;
+  const S pf = pw(se_f, e);
+  S g = h_c * pw(se_i, e) - pf / (R(1.0) - pf);
+  const R gv = val(g);
+  if (gv != gv || gv - gv != R(0.0)) g = h_c;  // torch.isinf / torch.isnan
+  return g;
+}
+
 // calc_aet, models/physics/lgar/aet.py:17-51 (0.75: GlobalParams.py:75; clamp upper bound = PET rate)
 template <typename S> __device__ __forceinline__ S aet_fn(const LayerK<S> &l, S pet, real_t<S> dt_h, S psi, real_t<S> wp_psi) {
   using R = real_t<S>;
@@ -300,7 +320,7 @@ template <typename S> __device__ __forceinline__ S aet_fn(const LayerK<S> &l, S 
 template <typename R> struct Glob {
   R dt_h, initial_psi, pdm, wp_psi, frozen;
   R giuh[LGAR_GMAX];
-  int nint, nsub, ng, search_mode, bottom_mode;
+  int nint, nsub, ng, search_mode, bottom_mode, closed_form;
   long long iter_cap;
 };
 
@@ -347,6 +367,10 @@ template <typename S, int NL, int FMAX> struct Column {
   __device__ Column(const ColParams<S, NL> &p, const Glob<R> &g, const FrontsView<S> &f) : P(p), G(g), F(f) {}
 
   __device__ __forceinline__ S cum_at(int k) const { return sel<S, NL>(P.cum, k); }
+  // calc_geff (lgar/green_ampt.py:19-99): trapezoid or closed form, per cfg.data.use_closed_form_G
+  __device__ __forceinline__ S capillary_drive(const LayerK<S> &lk, S theta1, S theta2) const {
+    return G.closed_form ? geff_closed(lk, theta1, theta2) : geff(lk, theta1, theta2, G.nint);
+  }
   __device__ __forceinline__ S cum_prev(int k) const {  // cum[k-1], 0 for k == 0
     S r = S(R(0.0));
 #pragma unroll
@@ -834,7 +858,7 @@ template <typename S, int NL, int FMAX> struct Column {
       S delta_theta = F.TH(i) - F.TH(i + 1);
       S dzdt = S(R(0.0));
       if (val(delta_theta) > R(0.0)) {
-        S g = geff(lk, theta_1, theta_2, G.nint);
+        S g = capillary_drive(lk, theta_1, theta_2);
         if (is_nan(val(g))) status |= LGAR_ST_NAN;
         const S ki = front_k(i, lk);
         if (k == 0) {
@@ -862,7 +886,7 @@ template <typename S, int NL, int FMAX> struct Column {
     const LayerK<S> l0 = pick_static(P, 0);
     S delta_theta = l0.te - F.TH(0);
     S tau = G.dt_h * l0.ksat / delta_theta;
-    S g = geff(l0, F.TH(0), l0.te, G.nint);
+    S g = capillary_drive(l0, F.TH(0), l0.te);
     if (is_nan(val(g))) status |= LGAR_ST_NAN;
     S dry = R(0.5) * (tau + sq(tau * tau + R(4.0) * tau * g));
     return mn(P.cum[0], dry);
@@ -914,7 +938,7 @@ template <typename S, int NL, int FMAX> struct Column {
     // quirk: with a fully saturated one-front top layer right after a layer crossing, nxt_i is a front of the
     // NEXT layer and Se > 1: the reference raises ValueError (negative pow base, physics/utils.py:25-27);
     // here the NaN is flagged and the IEEE min below drops it (all ponded water infiltrates).
-    if (nf != NL) g = geff(lk, F.TH(nxt_i < nf ? nxt_i : nf - 1), lk.te, G.nint);
+    if (nf != NL) g = capillary_drive(lk, F.TH(nxt_i < nf ? nxt_i : nf - 1), lk.te);
     if (is_nan(val(g))) status |= LGAR_ST_NAN | LGAR_ST_NEGBASE;
     S f_p;
     if (kfp == 0) {

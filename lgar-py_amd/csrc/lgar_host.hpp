@@ -19,6 +19,7 @@ template <typename R> inline Glob<R> make_glob(const LgarDims *d) {
   G.ng = d->n_giuh;
   G.search_mode = d->search_mode;
   G.bottom_mode = d->bottom_mode;
+  G.closed_form = d->use_closed_form_G;
   // literal searches (mode 0) are unbounded in the reference: generous cap.  In mode 1 the depth search needs a few
   // dozen iterations when it converges at all, so a diverging column (reference: endless loop) is cut off early.
   G.iter_cap = d->iter_cap > 0 ? d->iter_cap : (d->search_mode != 0 ? 5000LL : 2000000LL);

@@ -34,7 +34,7 @@ class LgarEngine:
     def __init__(self, alpha, n, ksat, theta_e, theta_r, thickness, *, n_columns=None, dt_h=1.0, num_subcycles=1,
                  initial_psi=2000.0, ponded_depth_max=0.0, wilting_point_psi=15495.0, frozen_factor=1.0, nint=120,
                  giuh_ordinates=(0.06, 0.51, 0.28, 0.12, 0.03), dtype=torch.float64, device="cuda:0",
-                 iter_cap=0, search_mode=1, bottom_mode=0):
+                 iter_cap=0, search_mode=1, bottom_mode=0, use_closed_form_G=False):
         self.device = torch.device(device)
         _require_gpu(self.device)
         self.lib = _capi.load()
@@ -72,6 +72,7 @@ class LgarEngine:
             d.giuh[i] = float(g)
         d.iter_cap = int(iter_cap)
         d.bottom_mode = int(bottom_mode)
+        d.use_closed_form_G = int(bool(use_closed_form_G))
 
         z = lambda *shape, dt=dtype: torch.zeros(*shape, dtype=dt, device=self.device)
         self.depth, self.theta, self.psi = z(FMAX, N), z(FMAX, N), z(FMAX, N)

@@ -47,8 +47,6 @@ class dpLGAR(nn.Module):
         single column into an ensemble; otherwise every column gets the table values of cfg.data.layer_soil_type."""
         super().__init__()
         self.cfg = cfg
-        if cfg.data.use_closed_form_G:
-            raise LgarError("use_closed_form_G=True is not supported (the bundled configs use the trapezoid Geff)")
         self.n_columns = int(n_columns if n_columns is not None else cfg.get("n_columns", 1) or 1)
         self.device = torch.device(cfg.device if str(cfg.device) != "cpu" else "cuda:0")
         self.dtype = torch.float32 if str(cfg.get("dtype", "float64")) in ("float32", "f32") else torch.float64
@@ -114,6 +112,7 @@ class dpLGAR(nn.Module):
                                  ponded_depth_max=float(self.ponded_depth_max),
                                  wilting_point_psi=float(cfg.data.wilting_point_psi), frozen_factor=ff,
                                  nint=int(cfg.constants.nint), giuh_ordinates=tuple(cfg.data.giuh_ordinates),
+                                 use_closed_form_G=bool(cfg.data.use_closed_form_G),
                                  dtype=self.dtype, device=self.device)
         self.c = self._soil_metrics(te, tr)
         from .autograd import StepTape

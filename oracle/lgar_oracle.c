@@ -147,8 +147,24 @@ static double th_k(const lgo_params *p, int k, double h, int *st) {
 static double se_k(const lgo_params *p, int k, double theta) { return lgo_se_from_theta(theta, p->theta_e[k], p->theta_r[k]); }
 static double h_k(const lgo_params *p, int k, double se, int *st) { return lgo_h_from_se(se, p->alpha[k], p->m[k], p->n[k], st); }
 static double K_k(const lgo_params *p, int k, double se, int *st) { return lgo_k_from_se(se, p->ksat[k], p->m[k], st); }
+/* calc_geff closed form, lgar/green_ampt.py:85-98; calc_bc_lambda / calc_bc_psib, physics/utils.py:54-64,84-99 */
+static double geff_closed(const lgo_params *p, int k, double theta1, double theta2, int *st) {
+  double m = p->m[k], alpha = p->alpha[k];
+  double pp = 1.0 + (2.0 / m);
+  double bc_lambda = 2.0 / (pp - 3.0);
+  double bc_psib = (pp + 3.0) * (147.8 + 8.1 * pp + 0.092 * pp * pp) / (2.0 * alpha * pp * (pp - 1.0) * (55.6 + 7.4 * pp + pp * pp));
+  double se_f = lgo_se_from_theta(theta1, p->theta_e[k], p->theta_r[k]);
+  double se_i = lgo_se_from_theta(theta2, p->theta_e[k], p->theta_r[k]);
+  double h_c = bc_psib * (2 + 3 * bc_lambda) / (1 + 3 * bc_lambda);
+  double e = (3 + 1 / bc_lambda);
+  double g = h_c * (spow(se_i, e, st)) - spow(se_f, e, st) / (1 - spow(se_f, e, st));
+  if (isinf(g) || isnan(g)) g = h_c;
+  return g;
+}
+
 static double geff_k(const lgo_params *p, lgo_state *s, int k, double t1, double t2) {
   s->n_geff++;
+  if (p->closed_form) return geff_closed(p, k, t1, t2, &s->status);
   return lgo_geff(t1, t2, p->alpha[k], p->n[k], p->m[k], p->ksat[k], p->theta_e[k], p->theta_r[k], p->nint, &s->status);
 }
 

@@ -48,6 +48,7 @@ typedef struct {
   int nint, num_subcycles, ngiuh;
   double giuh[LGO_GMAX];
   long iter_cap; /* cap for the two unbounded line searches */
+  int closed_form; /* cfg.data.use_closed_form_G (lgar/green_ampt.py:85-98) */
   int bottom_mode; /* 0 = reference (a front at the domain bottom kills the column); 1 = LGAR-C intent: percolate */
 } lgo_params;
 

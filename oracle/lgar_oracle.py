@@ -28,7 +28,7 @@ class Params(C.Structure):
                                    ("alpha", "n", "m", "ksat", "theta_e", "theta_r", "thick", "cum")] + [
         ("initial_psi", C.c_double), ("pdm", C.c_double), ("wp_psi", C.c_double), ("frozen_factor", C.c_double),
         ("dt_h", C.c_double), ("nint", C.c_int), ("num_subcycles", C.c_int), ("ngiuh", C.c_int),
-        ("giuh", C.c_double * GMAX), ("iter_cap", C.c_long), ("bottom_mode", C.c_int)]
+        ("giuh", C.c_double * GMAX), ("iter_cap", C.c_long), ("closed_form", C.c_int), ("bottom_mode", C.c_int)]
 
 
 class State(C.Structure):

@@ -84,7 +84,7 @@ def _write_soil_dat(soil, tmpdir):
     return out
 
 
-def build_cfg(forcing_csv, soil_dat, soil, pdm, subcycle_s, forcing_res_s, endtime_h, initial_psi=2000.0):
+def build_cfg(forcing_csv, soil_dat, soil, pdm, subcycle_s, forcing_res_s, endtime_h, initial_psi=2000.0, closed_form=False):
     from omegaconf import DictConfig
 
     root = yaml.safe_load(open(os.path.join(REF, "dpLGAR/config.yaml")))
@@ -100,6 +100,7 @@ def build_cfg(forcing_csv, soil_dat, soil, pdm, subcycle_s, forcing_res_s, endti
     cfg.data.layer_thickness = list(soil["thickness"])
     cfg.data.ponded_depth_max = pdm
     cfg.data.initial_psi = initial_psi
+    cfg.data.use_closed_form_G = bool(closed_form)
     cfg.models.subcycle_length = subcycle_s
     cfg.models.forcing_resolution = forcing_res_s
     cfg.models.endtime = endtime_h
@@ -154,7 +155,7 @@ ACC_NAMES = ["precip", "PET", "AET", "infiltration", "runoff", "percolation", "g
 
 
 def run_case(name, forcing, soil, pdm, subcycle_s, forcing_res_s, endtime_h, forcing_scale=1.0, grad=False,
-             record_fronts=True, initial_psi=2000.0):
+             record_fronts=True, initial_psi=2000.0, closed_form=False):
     torch.set_default_dtype(torch.float64)
     torch.manual_seed(0)
     from dpLGAR.data.Data import Data
@@ -163,7 +164,7 @@ def run_case(name, forcing, soil, pdm, subcycle_s, forcing_res_s, endtime_h, for
     tmpdir = tempfile.mkdtemp(prefix="lgar_golden_")
     fcsv = _fixed_forcing_csv(os.path.join(REF, "data", forcing), tmpdir)
     sdat = _write_soil_dat(soil, tmpdir)
-    cfg = build_cfg(fcsv, sdat, soil, pdm, subcycle_s, forcing_res_s, endtime_h, initial_psi)
+    cfg = build_cfg(fcsv, sdat, soil, pdm, subcycle_s, forcing_res_s, endtime_h, initial_psi, closed_form)
     data = Data(cfg)
     x = data.x * forcing_scale
     T = x.shape[0]
@@ -212,7 +213,7 @@ def run_case(name, forcing, soil, pdm, subcycle_s, forcing_res_s, endtime_h, for
         pdm=float(pdm), dt_h=float(cfg.models.subcycle_length_h), num_subcycles=int(cfg.models.num_subcycles),
         initial_psi=float(initial_psi), wilting_point_psi=float(cfg.data.wilting_point_psi),
         giuh_ordinates=np.array(cfg.data.giuh_ordinates), nint=int(cfg.constants.nint),
-        frozen_factor=float(cfg.constants.frozen_factor),
+        frozen_factor=float(cfg.constants.frozen_factor), closed_form=bool(closed_form),
         totals=np.array([_f(getattr(mb, nm)) for nm in ACC_NAMES[:8]]),
     )
     if record_fronts:
@@ -340,6 +341,10 @@ CASES["two_layer_phil_600"] = (run_case, dict(forcing=PH, soil=TWO, pdm=1.0, sub
 CASES["four_layer_synth1"] = (run_case, dict(forcing="forcing_data_synth_1.txt", soil=FOUR, pdm=0.0, subcycle_s=300, forcing_res_s=300, endtime_h=12.0))
 CASES["four_layer_phil_600"] = (run_case, dict(forcing=PH, soil=FOUR, pdm=2, subcycle_s=3600, forcing_res_s=3600, endtime_h=600.0))
 CASES["four_layer_synth0_600"] = (run_case, dict(forcing="forcing_data_synth_0.csv", soil=FOUR, pdm=0.0, subcycle_s=3600, forcing_res_s=3600, endtime_h=600.0))
+# closed-form capillary drive (lgar/green_ampt.py:85-98)
+CASES["closedG_synth1_phil"] = (run_case, dict(forcing="forcing_data_synth_1.txt", soil=PHIL, pdm=0.0, subcycle_s=300, forcing_res_s=300, endtime_h=12.0, closed_form=True))
+CASES["closedG_phil_hourly_600"] = (run_case, dict(forcing=PH, soil=PHIL, pdm=2, subcycle_s=3600, forcing_res_s=3600, endtime_h=600.0, closed_form=True))
+CASES["closedG_generic_synth0_400"] = (run_case, dict(forcing="forcing_data_synth_0.csv", soil=GENERIC, pdm=0.5, subcycle_s=3600, forcing_res_s=3600, endtime_h=400.0, closed_form=True))
 # perturbed-parameter ensembles: the roofline/ensemble configs use ±10 % columns
 for s in range(8):
     rng = np.random.default_rng(1000 + s)

@@ -26,7 +26,8 @@ def _engine(g, ncol, dtype, **kw):
                          dt_h=float(g["dt_h"]), num_subcycles=int(g["num_subcycles"]),
                          ponded_depth_max=float(g["pdm"]), initial_psi=float(g["initial_psi"]),
                          wilting_point_psi=float(g["wilting_point_psi"]), frozen_factor=float(g["frozen_factor"]),
-                         nint=int(g["nint"]), giuh_ordinates=tuple(g["giuh_ordinates"]), dtype=dtype, **kw)
+                         nint=int(g["nint"]), giuh_ordinates=tuple(g["giuh_ordinates"]), dtype=dtype,
+                         use_closed_form_G=bool(g["closed_form"]) if "closed_form" in g.files else False, **kw)
 
 
 def _forcing(g, ncol, sl=slice(None)):

@@ -13,10 +13,12 @@ RTOL = 1e-9
 
 
 def _params(g):
-    return O.make_params(g["alpha"], g["n"], g["ksat"], g["theta_e"], g["theta_r"], g["thickness"],
+    p = O.make_params(g["alpha"], g["n"], g["ksat"], g["theta_e"], g["theta_r"], g["thickness"],
                          pdm=float(g["pdm"]), dt_h=float(g["dt_h"]), num_subcycles=int(g["num_subcycles"]),
                          initial_psi=float(g["initial_psi"]), wp_psi=float(g["wilting_point_psi"]),
                          frozen_factor=float(g["frozen_factor"]), nint=int(g["nint"]), giuh=g["giuh_ordinates"])
+    p.closed_form = int(bool(g["closed_form"])) if "closed_form" in g.files else 0
+    return p
 
 
 def _rel(a, b):
