@@ -84,7 +84,7 @@ def _write_soil_dat(soil, tmpdir):
     return out
 
 
-def build_cfg(forcing_csv, soil_dat, soil, pdm, subcycle_s, forcing_res_s, endtime_h, initial_psi=2000.0, closed_form=False):
+def build_cfg(forcing_csv, soil_dat, soil, pdm, subcycle_s, forcing_res_s, endtime_h, initial_psi=2000.0, closed_form=False, frozen_factor=1):
     from omegaconf import DictConfig
 
     root = yaml.safe_load(open(os.path.join(REF, "dpLGAR/config.yaml")))
@@ -101,6 +101,7 @@ def build_cfg(forcing_csv, soil_dat, soil, pdm, subcycle_s, forcing_res_s, endti
     cfg.data.ponded_depth_max = pdm
     cfg.data.initial_psi = initial_psi
     cfg.data.use_closed_form_G = bool(closed_form)
+    cfg.constants.frozen_factor = frozen_factor
     cfg.models.subcycle_length = subcycle_s
     cfg.models.forcing_resolution = forcing_res_s
     cfg.models.endtime = endtime_h
@@ -155,7 +156,7 @@ ACC_NAMES = ["precip", "PET", "AET", "infiltration", "runoff", "percolation", "g
 
 
 def run_case(name, forcing, soil, pdm, subcycle_s, forcing_res_s, endtime_h, forcing_scale=1.0, grad=False,
-             record_fronts=True, initial_psi=2000.0, closed_form=False):
+             record_fronts=True, initial_psi=2000.0, closed_form=False, frozen_factor=1):
     torch.set_default_dtype(torch.float64)
     torch.manual_seed(0)
     from dpLGAR.data.Data import Data
@@ -164,7 +165,7 @@ def run_case(name, forcing, soil, pdm, subcycle_s, forcing_res_s, endtime_h, for
     tmpdir = tempfile.mkdtemp(prefix="lgar_golden_")
     fcsv = _fixed_forcing_csv(os.path.join(REF, "data", forcing), tmpdir)
     sdat = _write_soil_dat(soil, tmpdir)
-    cfg = build_cfg(fcsv, sdat, soil, pdm, subcycle_s, forcing_res_s, endtime_h, initial_psi, closed_form)
+    cfg = build_cfg(fcsv, sdat, soil, pdm, subcycle_s, forcing_res_s, endtime_h, initial_psi, closed_form, frozen_factor)
     data = Data(cfg)
     x = data.x * forcing_scale
     T = x.shape[0]
@@ -345,6 +346,11 @@ CASES["four_layer_synth0_600"] = (run_case, dict(forcing="forcing_data_synth_0.c
 CASES["closedG_synth1_phil"] = (run_case, dict(forcing="forcing_data_synth_1.txt", soil=PHIL, pdm=0.0, subcycle_s=300, forcing_res_s=300, endtime_h=12.0, closed_form=True))
 CASES["closedG_phil_hourly_600"] = (run_case, dict(forcing=PH, soil=PHIL, pdm=2, subcycle_s=3600, forcing_res_s=3600, endtime_h=600.0, closed_form=True))
 CASES["closedG_generic_synth0_400"] = (run_case, dict(forcing="forcing_data_synth_0.csv", soil=GENERIC, pdm=0.5, subcycle_s=3600, forcing_res_s=3600, endtime_h=400.0, closed_form=True))
+# frozen_factor != 1 (cfg.constants.frozen_factor: models/dpLGAR.py:57, Layer.py:1410-1412, 1466-1468, 1545)
+CASES["frozen07_synth1_phil"] = (run_case, dict(forcing="forcing_data_synth_1.txt", soil=PHIL, pdm=0.0, subcycle_s=300, forcing_res_s=300, endtime_h=12.0, frozen_factor=0.7))
+CASES["frozen07_phil_hourly_400"] = (run_case, dict(forcing=PH, soil=PHIL, pdm=2, subcycle_s=3600, forcing_res_s=3600, endtime_h=400.0, frozen_factor=0.7))
+# wetter initial condition
+CASES["psi500_synth1_generic"] = (run_case, dict(forcing="forcing_data_synth_1.txt", soil=GENERIC, pdm=0.0, subcycle_s=300, forcing_res_s=300, endtime_h=12.0, initial_psi=500.0))
 # perturbed-parameter ensembles: the roofline/ensemble configs use ±10 % columns
 for s in range(8):
     rng = np.random.default_rng(1000 + s)
