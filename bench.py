@@ -215,10 +215,10 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(N, T, args.dtype),
                          "traffic_note": "bytes per launch from separate rocprofv3 --pmc passes (profiles/r01/traffic.json), not live",
                          "algorithmic_bytes_per_launch": b_alg * N * T,
-                         "kernel": "lgar_forward_kernel<%s,3,16>" % ("float" if elem == 4 else "double"),
+                         "kernel": "lgar_forward_kernel<%s,3,12>" % ("float" if elem == 4 else "double"),
                          "kernel_ms": kern_ms, "alg_bytes_per_column_timestep": b_alg,
-                         "note": "path is VALU bound, not HBM bound (~1e3 flop/B; SQ_ACTIVE_INST_VALU ~97% of SIMD cycles in "
-                                 "profiles/r01/bench_v4_pmc_summary.txt); see DESIGN.md"},
+                         "note": "path is VALU bound, not HBM bound (~1e3 flop/B; see valu_roofline and DESIGN.md); "
+                                 "alg bytes use SURVEY 8(d)'s figure (F_MAX=16 state); the kernel's own state is F_MAX=12"},
             "valu_roofline": measured_valu(N, T, args.dtype),
             "faulted_columns": int(faulted.item()),
             "basin_runoff_total_cm": float(basin.sum().item()),
