@@ -166,10 +166,10 @@ def main():
         eng.reset()
         if i is not None:
             ev[i][0].record()  # same stream as the kernel launch (torch's current stream)
-        eng.forward(precip, pet, series=("runoff", "percolation"), out=out, check=False)
+        res = eng.forward(precip, pet, series=("runoff", "percolation"), out=out, basin=("runoff",), check=False)
         if i is not None:
             ev[i][1].record()
-        basin = out["runoff"].sum(dim=1, dtype=torch.float64)  # basin runoff per timestep [T]
+        basin = res["basin:runoff"]  # basin runoff per timestep [T] (fp64), reduced in the kernel epilogue
         if world > 1:
             all_reduce(basin)  # the only exchange of the path
         return basin

@@ -103,11 +103,22 @@ typedef struct {
   const void *precip, *pet;
 } LgarForcing;
 
-/* Optional per-step series, each [n_steps][n_columns] or NULL: the model accumulators as they stand
- * after forward() and before MassBalance.change_mass zeroes them (order = LGAR_NACC list).
- * series[4] (runoff) and series[5] (percolation) are forward()'s return pair (models/dpLGAR.py:299). */
+/* Optional per-step outputs.
+ * series[j]: [n_steps][n_columns] or NULL: the model accumulators as they stand after forward() and before
+ *   MassBalance.change_mass zeroes them (order = LGAR_NACC list).  series[4] (runoff) and series[5] (percolation)
+ *   are forward()'s return pair (models/dpLGAR.py:299).
+ * basin: [LGAR_NACC][n_steps] fp64 or NULL; for every bit j set in basin_mask,
+ *   basin[j][t] += sum over this launch's columns of weight[c] * accumulator_j[t][c]
+ *   (the caller zeroes it; what MassBalance.report_mass / the agent's y_hat aggregate over a basin).  Reduced in the
+ *   kernel (wave reduction + one fp64 atomic per wave and step): the [n_steps][n_columns] series need not exist.
+ *   Summation order across waves is not fixed, so values can differ in the last bits between runs.
+ * weights: [n_columns] (dtype) or NULL = 1: e.g. area fractions. */
 typedef struct {
   void *series[LGAR_NACC];
+  double *basin;
+  const void *weights;
+  uint32_t basin_mask;
+  uint32_t reserved;
 } LgarStepOut;
 
 const char *lgar_version(void);

@@ -44,7 +44,7 @@ class LgarForcing(C.Structure):
 
 
 class LgarStepOut(C.Structure):
-    _fields_ = [("series", C.c_void_p * NACC)]
+    _fields_ = [("series", C.c_void_p * NACC), ("basin", C.c_void_p), ("weights", C.c_void_p), ("basin_mask", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class LgarError(RuntimeError):

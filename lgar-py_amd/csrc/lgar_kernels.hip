@@ -24,6 +24,9 @@ template <typename R> struct KArgs {
   R *totals;                                              // [NACC][N]
   const R *precip, *pet;                                  // [T][N]
   R *series[LGAR_NACC];                                   // [T][N] or null
+  double *basin;                                          // [NACC][T] or null
+  const R *weights;                                       // [N] or null
+  unsigned basin_mask;
   int32_t *status;                                        // [N]
   Glob<R> G;
 };
@@ -100,14 +103,25 @@ __global__ __launch_bounds__(WAVE) void lgar_init_kernel(KArgs<R> a) {
   for (int j = 0; j < LGAR_NACC; j++) a.totals[j * N + c] = (j == 9) ? col.ending_volume : R(0);
 }
 
-// T x (dpLGAR.forward + MassBalance.change_mass) for every column; time loop inside the kernel
-template <typename R, int NL, int FMAX>
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+// T x (dpLGAR.forward + MassBalance.change_mass) for every column; time loop inside the kernel.
+// Lanes past the last column of a ragged tail wave integrate a copy of the last column (all 64 lanes stay active
+// for the wave reductions) and store nothing.
+// BASIN = false is the lean variant (no epilogue code, tail lanes exit at once); BASIN = true adds the basin epilogue.
+template <typename R, int NL, int FMAX, bool BASIN>
 __global__ __launch_bounds__(WAVE, (sizeof(R) == 4) ? 3 : 1) void lgar_forward_kernel(KArgs<R> a) {
   __shared__ WaveLDS<R, FMAX> lds;
   const int lane = threadIdx.x;
-  const size_t c = (size_t)blockIdx.x * WAVE + lane;
-  if (c >= (size_t)a.N) return;
   const size_t N = (size_t)a.N;
+  const size_t c0 = (size_t)blockIdx.x * WAVE + lane;
+  const bool live = c0 < N;
+  if (!BASIN && !live) return;
+  const size_t c = live ? c0 : N - 1;
   ColParams<R, NL> P;
   load_params<R, NL>(a, c, P);
   Column<R, NL, FMAX> col(P, a.G, make_view<R>(&lds.f[0][0][0], &lds.fl[0][0], FMAX, lane));
@@ -134,6 +148,8 @@ __global__ __launch_bounds__(WAVE, (sizeof(R) == 4) ? 3 : 1) void lgar_forward_k
   R tot[8];
 #pragma unroll
   for (int j = 0; j < 8; j++) tot[j] = a.totals[j * N + c];
+  double wgt = 0.0;
+  if (BASIN) wgt = live ? (a.weights ? (double)a.weights[c] : 1.0) : 0.0;
 
   // software prefetch: the next step's forcing is requested before this step is integrated, so its HBM latency
   // hides under ~10^4 cycles of VALU work
@@ -150,14 +166,26 @@ __global__ __launch_bounds__(WAVE, (sizeof(R) == 4) ? 3 : 1) void lgar_forward_k
     col.forward(precip, pet);
     const R acc[LGAR_NACC] = {col.a_precip, col.a_pet, col.a_aet, col.a_infil, col.a_runoff,
                               col.a_perc, col.a_giuh, col.a_disch, col.ponded_water, col.ending_volume};
+    if (live) {
 #pragma unroll
-    for (int j = 0; j < LGAR_NACC; j++)
-      if (a.series[j]) a.series[j][o] = acc[j];
+      for (int j = 0; j < LGAR_NACC; j++)
+        if (a.series[j]) a.series[j][o] = acc[j];
+    }
+    if (BASIN) {
+      // basin aggregation in the epilogue of the step (physics/MassBalance.py:77-108 over many columns)
+#pragma unroll
+      for (int j = 0; j < LGAR_NACC; j++)
+        if (a.basin_mask & (1u << j)) {
+          const double s = wave_sum(wgt * (double)acc[j]);
+          if (lane == 0) atomicAdd(&a.basin[(size_t)j * a.T + t], s);
+        }
+    }
 #pragma unroll
     for (int j = 0; j < 8; j++) tot[j] = tot[j] + acc[j];  // MassBalance.change_mass, MassBalance.py:31-44
     col.drain();
   }
 
+  if (!live) return;
   store_state<R, NL, FMAX>(a, c, col);
 #pragma unroll
   for (int j = 0; j < 8; j++) a.totals[j * N + c] = tot[j];
@@ -223,6 +251,9 @@ static KArgs<R> make_args(const LgarDims *d, const LgarParams *p, LgarState *s, 
   a.precip = f ? (const R *)f->precip : nullptr;
   a.pet = f ? (const R *)f->pet : nullptr;
   for (int j = 0; j < LGAR_NACC; j++) a.series[j] = o ? (R *)o->series[j] : nullptr;
+  a.basin = o ? o->basin : nullptr;
+  a.basin_mask = o ? o->basin_mask : 0u;
+  a.weights = o ? (const R *)o->weights : nullptr;
   a.status = status;
   a.G = make_glob<R>(d);
   return a;
@@ -243,7 +274,10 @@ static void launch_forward(const LgarDims *dims, const LgarParams *params, LgarS
                            const LgarStepOut *out, int32_t *status, hipStream_t st) {
   const unsigned grid = (unsigned)((dims->n_columns + WAVE - 1) / WAVE);
   KArgs<R> a = make_args<R>(dims, params, state, forcing, out, status);
-  hipLaunchKernelGGL((lgar_forward_kernel<R, NL, LGAR_FMAX>), dim3(grid), dim3(WAVE), 0, st, a);
+  if (a.basin != nullptr && a.basin_mask != 0u)
+    hipLaunchKernelGGL((lgar_forward_kernel<R, NL, LGAR_FMAX, true>), dim3(grid), dim3(WAVE), 0, st, a);
+  else
+    hipLaunchKernelGGL((lgar_forward_kernel<R, NL, LGAR_FMAX, false>), dim3(grid), dim3(WAVE), 0, st, a);
 }
 
 #define LGAR_BY_LAYERS(R, FN, ...)                 \

@@ -30,6 +30,13 @@ def basin_runoff(local_series, weights=None, group=None):
     return total
 
 
+def all_reduce_sum(t, group=None):
+    """In-place all-reduce(SUM) of an already locally reduced tensor (e.g. the kernel's in-epilogue basin sums [T])."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
 def reduce_parameter_gradients(grads, group=None):
     """Shared-parameter training: all-reduce(SUM) of the [L x 3] gradient scalars."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:

@@ -100,11 +100,13 @@ class LgarEngine:
                                           self.status.data_ptr(), self._dt, self._stream())
         _capi.check(rc, "lgar_state_init")
 
-    def forward(self, precip, pet, series=("runoff", "percolation"), out=None, check=True):
+    def forward(self, precip, pet, series=("runoff", "percolation"), out=None, check=True, basin=(), weights=None):
         """Advance every column by T forcing steps.  precip/pet: [T, N] cm/h on self.device.
 
         Returns {name: tensor[T, N]} for the requested per-step series (the model accumulators as they
-        stand after each forward(), before MassBalance.change_mass zeroes them)."""
+        stand after each forward(), before MassBalance.change_mass zeroes them).  basin: names whose per-step sum over
+        this engine's columns (optionally weighted by weights[N]) is reduced inside the kernel; returned under
+        "basin:<name>" as fp64 [T] tensors."""
         precip = torch.as_tensor(precip).to(self.device, self.dtype).contiguous()
         pet = torch.as_tensor(pet).to(self.device, self.dtype).contiguous()
         if precip.dim() == 1:
@@ -121,6 +123,19 @@ class LgarEngine:
                 raise LgarError("bad output buffer for series %r" % nm)
             res[nm] = buf
             so.series[j] = buf.data_ptr()
+        w = None
+        if basin:
+            block = torch.zeros(NACC, T, dtype=torch.float64, device=self.device)
+            so.basin = block.data_ptr()
+            for nm in basin:
+                j = ACC_NAMES.index(nm)
+                so.basin_mask |= 1 << j
+                res["basin:" + nm] = block[j]
+            if weights is not None:
+                w = torch.as_tensor(weights).to(self.device, self.dtype).contiguous()
+                if tuple(w.shape) != (self.N,):
+                    raise LgarError("weights must be [N]")
+                so.weights = w.data_ptr()
         self.dims.n_steps = T
         fo = _capi.LgarForcing(precip.data_ptr(), pet.data_ptr())
         with torch.cuda.device(self.device):

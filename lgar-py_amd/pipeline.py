@@ -7,13 +7,13 @@ integrates the previous chunk: two device buffers, no [T, N] array ever exists, 
 """
 import torch
 
-from .distributed import basin_runoff
+from .distributed import all_reduce_sum
 
 
-def run_streamed(engine, x, scale=None, pet_scale=None, chunk=512, series=("runoff",), reduce_basin=True):
+def run_streamed(engine, x, scale=None, pet_scale=None, chunk=512, series=("runoff",), reduce_basin=True, weights=None):
     """Integrate engine over the whole series x[T, 2] (cm/h; precip, PET).
 
-    scale / pet_scale: optional [N] per-column multipliers.  Returns {name: [T] basin sums (fp64, all-reduced across
+    scale / pet_scale: optional [N] per-column forcing multipliers; weights: optional [N] basin weights (area fractions).  Returns {name: [T] basin sums (fp64, all-reduced across
     ranks when torch.distributed is initialised)} if reduce_basin else {name: [T, N]} (only sensible for small N)."""
     dev, dt = engine.device, engine.dtype
     N = engine.N
@@ -49,9 +49,14 @@ def run_streamed(engine, x, scale=None, pet_scale=None, chunk=512, series=("runo
             stage(ci + 1, *bounds[ci + 1])  # expand the next chunk while this one is integrated
         b = ci % 2
         main.wait_event(ready[b])
-        out = engine.forward(bufs[b][0][: hi - lo], bufs[b][1][: hi - lo], series=series, check=False)
+        if reduce_basin:
+            # basin sums come out of the kernel epilogue: no [Tc, N] series buffer is written at all
+            out = engine.forward(bufs[b][0][: hi - lo], bufs[b][1][: hi - lo], series=(), basin=series, weights=weights,
+                                 check=False)
+        else:
+            out = engine.forward(bufs[b][0][: hi - lo], bufs[b][1][: hi - lo], series=series, check=False)
         freed[b].record(main)
         for nm in series:
-            outs[nm].append(basin_runoff(out[nm]) if reduce_basin else out[nm])
+            outs[nm].append(all_reduce_sum(out["basin:" + nm]) if reduce_basin else out[nm])
     engine.check_status()
     return {nm: (torch.cat(v) if v else torch.zeros(0, dtype=torch.float64, device=dev)) for nm, v in outs.items()}

@@ -116,3 +116,30 @@ def test_streamed_run_equals_single_shot():
     basin = run_streamed(c, x, scale=sc, chunk=256, series=("runoff",))["runoff"]
     assert basin.shape == (T,)
     assert torch.allclose(basin, full["runoff"].sum(1), rtol=1e-12, atol=1e-12)
+
+
+def test_in_kernel_basin_aggregation():
+    """LgarStepOut.basin: per-step basin sums reduced in the kernel epilogue (wave reduction + fp64 atomics) equal the
+    column sums of the per-step series, with and without weights, including a ragged tail wave."""
+    import lgar_py_amd as lg
+    from lgar_py_amd import workloads as W
+    for N in (70, 1000):
+        P = W.perturbed_columns(N, seed=41)
+        sc = W.forcing_scale(N, 0.5, 1.0, seed=42)
+        f = W.synth1_forcing()
+        pr = torch.tensor(f[:, 0:1] * sc[None, :])
+        pe = torch.zeros_like(pr)
+        w = torch.rand(N, dtype=torch.float64)
+        for dtype, tol in ((torch.float64, 1e-13), (torch.float32, 1e-6)):
+            eng = lg.LgarEngine(P["alpha"], P["n"], P["ksat"], P["theta_e"], P["theta_r"], P["thickness"],
+                                dt_h=300.0 / 3600.0, ponded_depth_max=0.0, dtype=dtype)
+            out = eng.forward(pr, pe, series=("runoff", "infiltration"), basin=("runoff", "infiltration", "discharge"),
+                              check=False)
+            for nm in ("runoff", "infiltration"):
+                ref = out[nm].double().sum(1)
+                assert torch.allclose(out["basin:" + nm], ref, rtol=tol, atol=tol * float(ref.abs().max())), (N, dtype, nm)
+            assert out["basin:discharge"].shape == (144,) and float(out["basin:discharge"].sum()) > 0
+            eng.reset()
+            outw = eng.forward(pr, pe, series=("runoff",), basin=("runoff",), weights=w, check=False)
+            refw = (outw["runoff"].double() * w.to(outw["runoff"].device)[None, :]).sum(1)
+            assert torch.allclose(outw["basin:runoff"], refw, rtol=tol * 10, atol=tol * 10 * float(refw.abs().max()))
