@@ -351,6 +351,25 @@ CASES["frozen07_synth1_phil"] = (run_case, dict(forcing="forcing_data_synth_1.tx
 CASES["frozen07_phil_hourly_400"] = (run_case, dict(forcing=PH, soil=PHIL, pdm=2, subcycle_s=3600, forcing_res_s=3600, endtime_h=400.0, frozen_factor=0.7))
 # wetter initial condition
 CASES["psi500_synth1_generic"] = (run_case, dict(forcing="forcing_data_synth_1.txt", soil=GENERIC, pdm=0.0, subcycle_s=300, forcing_res_s=300, endtime_h=12.0, initial_psi=500.0))
+# randomized configurations: USDA texture rows 0-11 of the reference's soil table (alpha, n, Ks from data/utils.py:108-180,
+# theta_r / theta_e from data/vG_default_params.dat:2-13), random thicknesses / ponding limit / forcing.  Some of them make
+# the reference crash (front at the domain bottom, negative pow base): the fixture then records the crash step.
+_TEX = [(0.01, 1.25, 0.612, 0.46, 0.1), (0.02, 1.42, 0.3348, 0.44, 0.08), (0.01, 1.47, 0.504, 0.4, 0.06),
+        (0.03, 1.75, 4.32, 0.39, 0.05), (0.04, 3.18, 26.64, 0.38, 0.05), (0.03, 1.21, 0.468, 0.39, 0.12),
+        (0.02, 1.33, 0.54, 0.38, 0.06), (0.03, 1.45, 1.584, 0.39, 0.04), (0.01, 1.68, 1.836, 0.49, 0.05),
+        (0.02, 1.32, 0.432, 0.48, 0.11), (0.01, 1.52, 0.468, 0.48, 0.09), (0.01, 1.66, 0.756, 0.44, 0.07)]
+for s_ in range(12):
+    rng = np.random.default_rng(7000 + s_)
+    L_ = int(rng.integers(2, 5))
+    rows = [_TEX[int(i)] for i in rng.integers(0, 12, L_)]
+    soil_ = dict(alpha=[r[0] for r in rows], n=[r[1] for r in rows], ksat=[r[2] for r in rows], theta_e=[r[3] for r in rows],
+                 theta_r=[r[4] for r in rows], thickness=[float(v) for v in rng.integers(15, 120, L_)])
+    five = bool(rng.random() < 0.4)
+    CASES["rand%02d" % s_] = (run_case, dict(
+        forcing=("forcing_data_synth_%d.txt" % int(rng.integers(1, 4))) if five else (PH if rng.random() < 0.5 else BU),
+        soil=soil_, pdm=float(rng.choice([0.0, 0.5, 2.0])), subcycle_s=300 if five else int(rng.choice([3600, 1800])),
+        forcing_res_s=300 if five else 3600, endtime_h=12.0 if five else 400.0,
+        forcing_scale=float(rng.choice([1.0, 1.0, 2.5])), initial_psi=float(rng.choice([2000.0, 800.0, 5000.0]))))
 # perturbed-parameter ensembles: the roofline/ensemble configs use ±10 % columns
 for s in range(8):
     rng = np.random.default_rng(1000 + s)

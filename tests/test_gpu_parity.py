@@ -44,27 +44,35 @@ def test_fp64_trajectory_vs_reference_golden(name, mode):
     import lgar_py_amd as lg
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     ncol = 67  # one full wave + a ragged tail
+    crash = int(g["crash_step"])
+    T = crash if crash >= 0 else g["forcing"].shape[0]
     eng = _engine(g, ncol, torch.float64, search_mode=mode)
     assert abs(float(eng.ending_volume[0]) - float(g["init_volume"])) <= 1e-9
-    pr, pe = _forcing(g, ncol)
+    pr, pe = _forcing(g, ncol, slice(0, T))
     out = eng.forward(pr, pe, series=lg.ACC_NAMES)
     for j, nm in enumerate(lg.ACC_NAMES):
         got = out[nm].cpu().numpy()
-        assert _rel(got[:, 0], g["acc"][:, j]).max() <= 1e-6, nm
+        assert _rel(got[:, 0], g["acc"][:T, j]).max() <= 1e-6, nm
         assert (got == got[:, :1]).all(), "replicated columns must be bit-identical"
     fr = eng.fronts()
-    nf = int(g["nfronts"][-1])
+    nf = int(g["nfronts"][T - 1])
     assert (fr["n_fronts"] == nf).all()
-    assert _rel(fr["depth"][:nf, 0], g["fronts"][-1, :nf, 0]).max() <= 1e-6
-    assert _rel(fr["theta"][:nf, 0], g["fronts"][-1, :nf, 1]).max() <= 1e-6
-    assert _rel(fr["psi"][:nf, 0], g["fronts"][-1, :nf, 2], 1e-3).max() <= 1e-5
-    assert _rel(fr["k"][:nf, 0], g["fronts"][-1, :nf, 3], 1e-12).max() <= 1e-5   # K(theta), deepest front keeps its initial K
-    assert _rel(fr["dzdt"][:nf, 0], g["fronts"][-1, :nf, 4], 1e-9).max() <= 1e-5
-    assert (fr["layer"][:nf, 0] == g["front_layer"][-1, :nf]).all()
-    assert (fr["to_bottom"][:nf, 0] == g["front_bottom"][-1, :nf]).all()
+    assert _rel(fr["depth"][:nf, 0], g["fronts"][T - 1, :nf, 0]).max() <= 1e-6
+    assert _rel(fr["theta"][:nf, 0], g["fronts"][T - 1, :nf, 1]).max() <= 1e-6
+    assert _rel(fr["psi"][:nf, 0], g["fronts"][T - 1, :nf, 2], 1e-3).max() <= 1e-5
+    assert _rel(fr["k"][:nf, 0], g["fronts"][T - 1, :nf, 3], 1e-12).max() <= 1e-5   # K(theta), deepest front keeps its initial K
+    assert _rel(fr["dzdt"][:nf, 0], g["fronts"][T - 1, :nf, 4], 1e-9).max() <= 1e-5
+    assert (fr["layer"][:nf, 0] == g["front_layer"][T - 1, :nf]).all()
+    assert (fr["to_bottom"][:nf, 0] == g["front_bottom"][T - 1, :nf]).all()
     # run totals (what MassBalance accumulates)
     for j in range(8):
-        assert _rel(float(eng.totals[j, 0]), g["acc"][:, j].sum()) <= 1e-6
+        assert _rel(float(eng.totals[j, 0]), g["acc"][:T, j].sum()) <= 1e-6
+    if crash >= 0:
+        # the reference raised at this step (ValueError / AttributeError): every column must fault here too
+        pr1, pe1 = _forcing(g, ncol, slice(T, T + 1))
+        with pytest.raises(lg.LgarStatusError):
+            eng.forward(pr1, pe1)
+        assert bool((eng.status != 0).all())
 
 
 def test_config2_10k_replicated_phillipsburg_fp64():
