@@ -1,7 +1,7 @@
 """BASELINE configs[4]: 100k-column vG parameter ensemble, forward + backward through the HIP kernels (dev tool).
 Prints fwd and fwd+bwd column-timesteps/s."""
 import os, sys, time, json
-import numpy as np, torch
+import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lgar_py_amd import workloads as W
 from lgar_py_amd.autograd import lgar_series
