@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.environ.get("LGAR_LIB") or os.path.join(CSRC, "liblgar_hip.so")
 SOURCES = ["lgar_kernels.hip", "lgar_tangent.hip"]
-HEADERS = ["lgar_device.hpp", "lgar_dual.hpp", os.path.join("..", "..", "include", "lgar.h")]
+HEADERS = ["lgar_device.hpp", "lgar_dual.hpp", "lgar_math.hpp", "lgar_host.hpp", os.path.join("..", "..", "include", "lgar.h")]
 # -ffp-contract=off: expression rounding follows the reference's Python (no FMA contraction)
 # fp32 division stays correctly rounded: with the rcp-based fast divide x/x != 1, Se = (theta-theta_r)/(theta_e-theta_r)
 # exceeds 1 at saturation and 8 % of perturbed columns fault (measured), for no speed gain.

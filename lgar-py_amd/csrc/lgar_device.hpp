@@ -15,6 +15,7 @@
 #include <stdint.h>
 
 #include "../../include/lgar.h"
+#include "lgar_math.hpp"
 
 namespace lgar {
 
@@ -28,12 +29,10 @@ template <typename S> using real_t = typename Real<S>::type;
 
 __device__ __forceinline__ double val(double x) { return x; }
 __device__ __forceinline__ float val(float x) { return x; }
-#ifndef LGAR_F64_FAST_POW
-__device__ __forceinline__ double pw(double x, double y) { return pow(x, y); }  // ocml, < 1 ulp
+#ifdef LGAR_F64_LIBM
+__device__ __forceinline__ double pw(double x, double y) { return pow(x, y); }  // ocml, < 1 ulp, ~200 instructions
 #else
-// exp2(y log2 x): ~|y log2 x| ulps (1e-14 relative here).  Measured +5 % on the fp64 kernel once Geff is fused, with
-// the same parity: not worth leaving the < 1 ulp pow for the state updates, so it is off by default.
-__device__ __forceinline__ double pw(double x, double y) { return exp2(y * log2(x)); }
+__device__ __forceinline__ double pw(double x, double y) { return fast_pow(x, y); }  // lgar_math.hpp, ~1e-14 relative
 #endif
 // fp32: v_log_f32 / v_exp_f32 (quarter-rate transcendentals), ~2-3 ulp for the exponents used here
 __device__ __forceinline__ float pw(float x, float y) { return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)); }
@@ -180,8 +179,13 @@ template <typename S> __device__ __forceinline__ S geff(const LayerK<S> &l, S th
 // reference's running sum h2 += dh.
 __device__ __forceinline__ float lg2(float x) { return __builtin_amdgcn_logf(x); }
 __device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
+#ifdef LGAR_F64_LIBM
 __device__ __forceinline__ double lg2(double x) { return log2(x); }
 __device__ __forceinline__ double ex2(double x) { return exp2(x); }
+#else
+__device__ __forceinline__ double lg2(double x) { return fast_log2(x); }
+__device__ __forceinline__ double ex2(double x) { return fast_exp2(x); }
+#endif
 
 template <typename S> __device__ __forceinline__ S geff_fused(const LayerK<S> &l, S theta1, S theta2, int nint) {
   using R = real_t<S>;

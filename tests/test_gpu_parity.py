@@ -211,7 +211,9 @@ def test_leaf_kats_on_gpu():
         assert _rel(got, want, 1e-300).max() <= tol, op
     t1, t2 = g["geff_theta1"].ravel(), g["geff_theta2"].ravel()
     got = lg.leaf_batch("geff", t1, t2, **bc(g["geff"].shape[1])).cpu().numpy().reshape(g["geff"].shape)
-    assert _rel(got, g["geff"], 1e-300).max() <= 1e-10
+    # fused-node trapezoid with the lean (~2 ulp) log2/exp2: the extreme pairs (Se 0.02 -> 1, integral dominated by the
+    # last node at h ~ 1e-5 cm) are the least well conditioned
+    assert _rel(got, g["geff"], 1e-300).max() <= 1e-8
     # fp32 fast-pow path: a few ulp of fp32 on the trapezoid
     # (inputs clamped to theta_e after the cast: a theta rounded above theta_e has Se > 1, which is outside the domain)
     te32 = bc(g["geff"].shape[1])["theta_e"].astype(np.float32)
