@@ -89,7 +89,9 @@ def cpu_baseline(target_s=12.0):
     n = (n // 64) * 64
     t = run(n)
     return {"value": n * T / t, "unit": "column-timesteps/s", "cores": cores, "kind": "port",
-            "sample": "%d columns x %d steps of the same synth_1 workload, fp64 C oracle, OpenMP, %.1f s" % (n, T, t)}
+            "sample": "%d columns x %d steps of the same synth_1 workload, fp64 C oracle, OpenMP, %.1f s" % (n, T, t),
+            "reference_pytorch_cpu_loop": "10.9 column-timesteps/s on this forcing shape, 1 core (BASELINE.md section 2: observed "
+                                          "in the survey container; the Python reference cannot travel to the GPU box)"}
 
 
 def main():
