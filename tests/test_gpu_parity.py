@@ -348,3 +348,46 @@ def test_percolating_bottom_boundary_matches_oracle():
         # (this 12 cm toy column does not close its balance exactly: the reference clamps layer-0 fronts to the column
         #  depth, Layer.py:456-457, which drops their overshoot)
         assert abs(v0 + t[0] - t[4] - t[2] - t[8] - t[5] - t[9]) <= 0.1
+
+
+@pytest.mark.parametrize("name", ["phil_hourly_3000", "synth0_phil_1500", "four_layer_synth0_600", "bushland_hourly_1500"])
+def test_single_step_transitions_from_injected_reference_states(name):
+    """Per-branch state transitions: every column of ONE launch starts from a different state captured from the
+    reference (written straight into the engine's state tensors) and takes one forward(); outputs must equal the
+    reference's next step.  Covers create / insert_water / in-layer moves / base case / merge / layer crossing /
+    dry-over-wet as (state_in, forcing) -> state_out pairs, and the HBM -> LDS state load path."""
+    import lgar_py_amd as lg
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    nf = g["nfronts"]
+    T = len(nf)
+    ks = sorted(set([k for k in range(T - 1) if nf[k + 1] != nf[k]] + list(range(0, T - 1, 17))))
+    N = len(ks)
+    eng = _engine(g, N, torch.float64)
+    F = eng.depth.shape[0]
+    fr = np.transpose(g["fronts"][ks][:, :F, :], (2, 1, 0))  # [5, F, N]
+    dev = eng.device
+    for j, t in enumerate((eng.depth, eng.theta, eng.psi, eng.k, eng.dzdt)):
+        t.copy_(torch.tensor(fr[j], device=dev))
+    lay = g["front_layer"][ks][:, :F].T.astype(np.int16)
+    bot = g["front_bottom"][ks][:, :F].T.astype(np.int16)
+    flags = np.where(lay >= 0, lay | (bot << 7), 0).astype(np.uint8)
+    eng.flags.copy_(torch.tensor(flags, device=dev))
+    eng.n_fronts.copy_(torch.tensor(nf[ks].astype(np.int32), device=dev))
+    eng.scalars[0].copy_(torch.tensor(g["acc"][ks, 8], device=dev))
+    eng.scalars[1].copy_(torch.tensor(g["prev_precip"][ks], device=dev))
+    eng.scalars[2].copy_(torch.tensor(g["acc"][ks, 9], device=dev))
+    eng.scalars[3:8].copy_(torch.tensor(g["giuh_queue"][ks].T, device=dev))
+    nxt = [k + 1 for k in ks]
+    pr = torch.tensor(g["forcing"][nxt, 0][None, :])
+    pe = torch.tensor(g["forcing"][nxt, 1][None, :])
+    out = eng.forward(pr, pe, series=lg.ACC_NAMES)
+    for j, nm in enumerate(lg.ACC_NAMES):
+        got = out[nm][0].cpu().numpy()
+        assert _rel(got, g["acc"][nxt, j]).max() <= 1e-6, nm
+    res = eng.fronts()
+    assert (res["n_fronts"] == nf[nxt]).all()
+    for c, k in enumerate(nxt):
+        n = int(nf[k])
+        assert _rel(res["depth"][:n, c], g["fronts"][k, :n, 0]).max() <= 1e-6, k
+        assert _rel(res["theta"][:n, c], g["fronts"][k, :n, 1]).max() <= 1e-6, k
+        assert (res["layer"][:n, c] == g["front_layer"][k, :n]).all() and (res["to_bottom"][:n, c] == g["front_bottom"][k, :n]).all()
