@@ -557,13 +557,26 @@ template <typename S, int NL, int FMAX> struct Column {
       R factor = R(1.0);
       S depth_new = F.Z(fdd);
       // search_mode 1: the column mass is LINEAR in this one depth (slope = theta_fdd - theta_next, or theta_fdd for
-      // the last front of a layer), so all but the last two fixed steps of each up/down run are taken in one jump;
-      // the reference's loop then finishes on the true mass with its own termination test.
+      // the last front of a layer).  (i) All but the last two fixed steps of each up/down run are taken in one jump;
+      // (ii) inside the loop the mass is evaluated from the linear model instead of re-summing the front table; when
+      // the model says "converged" the true mass is summed once and, if the reference's termination test does not hold
+      // on it, the reference's loop simply continues on true sums.
       const bool nxt_same = (fdd + 1 < nf) && (F.layer(fdd + 1) == F.layer(fdd));
-      const R slope = nxt_same ? val(F.TH(fdd)) - val(F.TH(fdd + 1)) : val(F.TH(fdd));
+      const S slope_s = nxt_same ? F.TH(fdd) - F.TH(fdd + 1) : F.TH(fdd);
+      const R slope = val(slope_s);
       const bool jump = (G.search_mode != 0) && (slope > R(0.0));
+      bool model = jump;
+      const S m0 = current_mass, d0 = depth_new;
       long long it = 0;
-      while (ab(err - Tol<R>::mass) > Tol<R>::mass) {
+      while (true) {
+        if (!(ab(err - Tol<R>::mass) > Tol<R>::mass)) {
+          if (!model) break;
+          F.Z(fdd) = depth_new;  // verify on the true mass; from here on the loop is the reference's own
+          current_mass = mass_balance();
+          err = ab(val(current_mass) - val(mass_timestep));
+          model = false;
+          continue;
+        }
         if (++it > G.iter_cap) { status |= LGAR_ST_ITERCAP; break; }
         R before = val(depth_new);
         if (val(current_mass) < val(mass_timestep)) {
@@ -582,10 +595,15 @@ template <typename S, int NL, int FMAX> struct Column {
           depth_new = depth_new - (R(0.01) * factor);
         }
         if (sizeof(R) == 4 && val(depth_new) == before && factor < R(1e-6)) break;  // fp32: step below resolution
-        F.Z(fdd) = depth_new;
-        current_mass = mass_balance();
+        if (model) {
+          current_mass = m0 + slope_s * (depth_new - d0);
+        } else {
+          F.Z(fdd) = depth_new;
+          current_mass = mass_balance();
+        }
         err = ab(val(current_mass) - val(mass_timestep));
       }
+      if (model) F.Z(fdd) = depth_new;  // left the loop (cap / resolution) while still on the model
     }
   }
 
