@@ -36,6 +36,16 @@ __device__ __forceinline__ double pw(double x, double y) { return fast_pow(x, y)
 #endif
 // fp32: v_log_f32 / v_exp_f32 (quarter-rate transcendentals), ~2-3 ulp for the exponents used here
 __device__ __forceinline__ float pw(float x, float y) { return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)); }
+// log2 / exp2 (fused Geff node, dual-number pow)
+__device__ __forceinline__ float lg2(float x) { return __builtin_amdgcn_logf(x); }
+__device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
+#ifdef LGAR_F64_LIBM
+__device__ __forceinline__ double lg2(double x) { return log2(x); }
+__device__ __forceinline__ double ex2(double x) { return exp2(x); }
+#else
+__device__ __forceinline__ double lg2(double x) { return fast_log2(x); }
+__device__ __forceinline__ double ex2(double x) { return fast_exp2(x); }
+#endif
 __device__ __forceinline__ double sq(double x) { return sqrt(x); }
 __device__ __forceinline__ float sq(float x) { return __builtin_amdgcn_sqrtf(x); }
 __device__ __forceinline__ double ab(double x) { return fabs(x); }
@@ -177,15 +187,6 @@ template <typename S> __device__ __forceinline__ S geff(const LayerK<S> &l, S th
 // is 1 anyway.)  fp32 places the nodes directly (h_i + (i+1) dh, last node = h_f): its running sum drifts by ~nint
 // ulps of h_i, cm-scale for very dry soil, and the last trapezoid dominates the integral; fp64 keeps the
 // reference's running sum h2 += dh.
-__device__ __forceinline__ float lg2(float x) { return __builtin_amdgcn_logf(x); }
-__device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
-#ifdef LGAR_F64_LIBM
-__device__ __forceinline__ double lg2(double x) { return log2(x); }
-__device__ __forceinline__ double ex2(double x) { return exp2(x); }
-#else
-__device__ __forceinline__ double lg2(double x) { return fast_log2(x); }
-__device__ __forceinline__ double ex2(double x) { return fast_exp2(x); }
-#endif
 
 template <typename S> __device__ __forceinline__ S geff_fused(const LayerK<S> &l, S theta1, S theta2, int nint) {
   using R = real_t<S>;

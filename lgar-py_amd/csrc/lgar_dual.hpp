@@ -45,9 +45,11 @@ template <typename R> __device__ __forceinline__ Dual<R> operator-(const Dual<R>
 
 // torch.pow: d/dx = y x^(y-1), d/dy = x^y ln x; at x <= 0 the tangent is dropped (the value path flags NaN there)
 template <typename R> __device__ __forceinline__ Dual<R> pw(const Dual<R> &x, const Dual<R> &y) {
-  const R v = pw(x.v, y.v);
+  // one log2 serves both the value and d/dy: x^y = 2^(y log2 x), ln x = ln 2 * log2 x
+  const R l2 = lg2(x.v);
+  const R v = ex2(y.v * l2);
   R d = R(0);
-  if (x.v > R(0)) d = v * (y.d * log(x.v) + y.v * x.d / x.v);
+  if (x.v > R(0)) d = v * (y.d * (R(0.6931471805599453) * l2) + y.v * x.d / x.v);
   return Dual<R>(v, d);
 }
 template <typename R> __device__ __forceinline__ Dual<R> sq(const Dual<R> &x) {
