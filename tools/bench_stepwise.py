@@ -1,0 +1,31 @@
+"""Drop-in latency (dev tool): the reference's row-by-row agent loop, N = 1, Phillipsburg hourly, no_grad and grad mode."""
+import os, sys, time, json, tempfile
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from test_host_io import write_forcing, write_soil_dat
+from lgar_py_amd import config
+from lgar_py_amd.data import Data
+from lgar_py_amd.model import MassBalance, dpLGAR
+g = np.load(os.path.join(ROOT, "tests", "golden", "phil_hourly_3000.npz"))
+tmp = tempfile.mkdtemp(); os.makedirs(os.path.join(tmp, "data"))
+n = 300
+cfg = config.load_config(cwd=tmp, overrides={"data.forcing_file": write_forcing(os.path.join(tmp, "data", "f.csv"), g["forcing"][:n]),
+                                             "data.soil_params_file": write_soil_dat(os.path.join(tmp, "data", "s.dat")), "models.endtime": float(n)})
+data = Data(cfg)
+res = {}
+for mode in ("no_grad", "grad"):
+    model = dpLGAR(cfg); mb = MassBalance(cfg, model)
+    ctx = torch.no_grad() if mode == "no_grad" else torch.enable_grad()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    with ctx:
+        ys = []
+        for i in range(n):
+            r, _ = model(data[i][0]); ys.append(r); mb.change_mass(model)
+    torch.cuda.synchronize(); t1 = time.perf_counter()
+    if mode == "grad":
+        loss = torch.stack(ys).sum() + mb.AET * 0
+        loss.backward(); torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    res[mode] = dict(steps_per_s=n / (t1 - t0), backward_s=t2 - t1)
+print(json.dumps(res))
