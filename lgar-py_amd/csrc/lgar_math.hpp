@@ -39,7 +39,11 @@ __device__ __forceinline__ double fast_log2(double x) {
   const bool lo = m < 0.70710678118654752440;
   m = lo ? m * 2.0 : m;     // m in [sqrt(1/2), sqrt(2))
   e = lo ? e - 1 : e;
-  const double s = (m - 1.0) / (m + 1.0);  // |s| <= 0.1716
+  // (m - 1) / (m + 1) with v_rcp_f64 + one Newton step instead of the ~12-instruction IEEE divide
+  const double d = m + 1.0;
+  double rc = __builtin_amdgcn_rcp(d);
+  rc = fma(fma(-d, rc, 1.0), rc, rc);
+  const double s = (m - 1.0) * rc;  // |s| <= 0.1716
   const double z = s * s;
   double p = 4.7619047619047616e-02;        // 1/21
   p = fma(p, z, 5.2631578947368418e-02);    // 1/19
