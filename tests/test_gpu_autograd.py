@@ -198,3 +198,20 @@ def test_agent_twin_experiment_reduces_loss(tmp_path):
     with torch.no_grad():
         m.alpha[0].fill_(0.02)
     assert abs(float(rb([m.alpha, m.n, m.ksat, m.ponded_depth_max])) - 0.005) < 1e-12
+
+
+def test_fp32_gradients_close_to_reference():
+    """The fp32 tangent kernel on the same case as the reference's autograd fixture: gradients within 2 % of fp64's."""
+    from lgar_py_amd.autograd import lgar_series
+    g = np.load(os.path.join(GOLDEN, "grad_synth0_12h.npz"))
+    P, pr, pe, ekw = _setup(g, 2, dtype=torch.float32)
+    for k in ("alpha", "n", "ksat"):
+        P[k].requires_grad_(True)
+    runoff, _ = lgar_series(P["alpha"], P["n"], P["ksat"], P["theta_e"], P["theta_r"], P["thickness"], pr, pe, **ekw)
+    loss = torch.mean(runoff[:, 0] ** 2)
+    assert abs(float(loss) - float(g["loss"])) <= 1e-3 * float(g["loss"])
+    loss.backward()
+    for k, ref in (("alpha", g["d_alpha"]), ("n", g["d_n"]), ("ksat", g["d_ksat"])):
+        ref = np.nan_to_num(ref, nan=0.0)
+        got = P[k].grad[:, 0].double().cpu().numpy()
+        assert np.abs(got - ref).max() <= 2e-2 * np.abs(ref).max(), (k, got, ref)
