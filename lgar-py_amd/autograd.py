@@ -12,6 +12,41 @@ import torch
 from .engine import LgarEngine
 
 KINDS = ("alpha", "n", "ksat")
+# below this many (column, direction) pairs all directions of a backward pass ride as extra columns of ONE tangent
+# launch (latency-bound small jobs: the reference's single-column training loop); above it one launch per direction
+BATCH_DIRECTIONS_MAX_COLUMNS = 1 << 16
+
+
+def parameter_vjp(eng, precip, pet, w_runoff, w_perc, wanted):
+    """Vector-Jacobian product for every (kind, layer) in `wanted` (list of (kind, l)).
+    Returns {(kind, l): grad[N]}.  Columns are independent, so for small jobs the directions are laid side by side as
+    len(wanted) * N columns of a single launch; large jobs loop over directions (same total work, N-column memory)."""
+    L, N, D = eng.L, eng.N, len(wanted)
+    out = {}
+    if D == 0:
+        return out
+    if D * N <= BATCH_DIRECTIONS_MAX_COLUMNS and D > 1:
+        rep = lambda t: t.repeat(1, D)
+        d = eng.dims
+        big = LgarEngine(rep(eng.alpha), rep(eng.n), rep(eng.ksat), rep(eng.theta_e), rep(eng.theta_r), rep(eng.thickness),
+                         dt_h=d.dt_h, num_subcycles=d.num_subcycles, initial_psi=d.initial_psi,
+                         ponded_depth_max=d.ponded_depth_max, wilting_point_psi=d.wilting_point_psi,
+                         frozen_factor=d.frozen_factor, nint=d.nint, giuh_ordinates=tuple(d.giuh[i] for i in range(d.n_giuh)),
+                         dtype=eng.dtype, device=eng.device, iter_cap=d.iter_cap, search_mode=d.search_mode,
+                         bottom_mode=d.bottom_mode, use_closed_form_G=bool(d.use_closed_form_G))
+        dirs = {k: torch.zeros(L, D * N, dtype=eng.dtype, device=eng.device) for k in KINDS}
+        for b, (kind, l) in enumerate(wanted):
+            dirs[kind][l, b * N:(b + 1) * N] = 1.0
+        tile = lambda t: None if t is None else t.repeat(1, D)
+        g, _, _ = big.tangent(dirs, tile(precip), tile(pet), w_runoff=tile(w_runoff), w_perc=tile(w_perc))
+        for b, key in enumerate(wanted):
+            out[key] = g[b * N:(b + 1) * N]
+        return out
+    for kind, l in wanted:
+        dmat = torch.zeros(L, N, dtype=eng.dtype, device=eng.device)
+        dmat[l] = 1.0
+        out[(kind, l)], _, _ = eng.tangent({kind: dmat}, precip, pet, w_runoff=w_runoff, w_perc=w_perc)
+    return out
 
 
 class LgarSeriesFunction(torch.autograd.Function):
@@ -35,17 +70,14 @@ class LgarSeriesFunction(torch.autograd.Function):
     def backward(ctx, g_runoff, g_perc):
         eng = ctx.engine
         precip, pet = ctx.forcing
+        wanted = [(kind, l) for ki, kind in enumerate(KINDS) if ctx.needs_input_grad[ki] for l in range(eng.L)]
+        vj = parameter_vjp(eng, precip, pet, g_runoff, g_perc, wanted)
         grads = []
         for ki, kind in enumerate(KINDS):
             if not ctx.needs_input_grad[ki]:
                 grads.append(None)
                 continue
-            g = torch.zeros(eng.L, eng.N, dtype=eng.dtype, device=eng.device)
-            for l in range(eng.L):
-                d = torch.zeros(eng.L, eng.N, dtype=eng.dtype, device=eng.device)
-                d[l] = 1.0
-                g[l], _, _ = eng.tangent({kind: d}, precip, pet, w_runoff=g_runoff, w_perc=g_perc)
-            grads.append(g.to(ctx.in_dtypes[ki]))
+            grads.append(torch.stack([vj[(kind, l)] for l in range(eng.L)]).to(ctx.in_dtypes[ki]))
         return (*grads, None, None, None, None, None, None)
 
 
@@ -68,6 +100,9 @@ class StepTape:
         self.reset()
 
     def reset(self):
+        for h in getattr(self, "handles", []):
+            h.remove()
+        self.handles = []    # hook handles of the leaves handed out
         self.x = []          # forcing chunks [Tc, N, 2] since the last set_internal_states()
         self.w = {}          # (chunk, 0|1) -> gradient received, [Tc, N]
         self.queued = False
@@ -79,7 +114,7 @@ class StepTape:
         outs = []
         for which, v in enumerate((runoff_chunk, perc_chunk)):
             leaf = v.detach().clone().requires_grad_(True)
-            leaf.register_hook(lambda g, ci=ci, which=which: self._on_grad(ci, which, g))
+            self.handles.append(leaf.register_hook(lambda g, ci=ci, which=which: self._on_grad(ci, which, g)))
             outs.append(leaf)
         return outs
 
@@ -108,15 +143,21 @@ class StepTape:
         self.w = {}
         precip, pet = X[:, :, 0].contiguous(), X[:, :, 1].contiguous()
         ff = float(m.cfg.constants.frozen_factor)
-        for kind, plist in (("alpha", m.alpha), ("n", m.n), ("ksat", m.ksat)):
+        plists = (("alpha", m.alpha), ("n", m.n), ("ksat", m.ksat))
+        wanted = [(kind, l) for kind, plist in plists for l, p in enumerate(plist) if p.requires_grad]
+        vj = parameter_vjp(eng, precip, pet, W[0], W[1], wanted)
+        for kind, plist in plists:
             for l, p in enumerate(plist):
                 if not p.requires_grad:
                     continue
-                d = torch.zeros(eng.L, eng.N, dtype=eng.dtype, device=eng.device)
-                d[l] = 1.0
-                g, _, _ = eng.tangent({kind: d}, precip, pet, w_runoff=W[0], w_perc=W[1])
+                g = vj[(kind, l)]
                 if kind == "ksat":
                     g = g / ff  # the Parameter already carries frozen_factor (models/dpLGAR.py:57)
                 g = g.to(torch.float64).to(p.device)
                 g = g.sum() if p.dim() == 0 else g
                 p.grad = g.to(p.dtype) if p.grad is None else p.grad + g.to(p.dtype)
+        # the recorded series is consumed: drop the hooks (they hold this tape, the tape holds the model) so nothing
+        # autograd-related is left for interpreter shutdown to untangle
+        for h in self.handles:
+            h.remove()
+        self.handles = []
