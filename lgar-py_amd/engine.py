@@ -61,6 +61,14 @@ class LgarEngine:
                 raise LgarError("parameter shapes differ: expected %s, got %s" % ((L, N), tuple(t.shape)))
         if len(giuh_ordinates) > GMAX:
             raise LgarError("at most %d GIUH ordinates" % GMAX)
+        # physical sanity of the soil table (the reference would run into NaNs / negative pow bases much later)
+        bad = [nm for nm, ok in (("alpha > 0", self.alpha > 0), ("n > 1", self.n > 1), ("ksat > 0", self.ksat > 0),
+                                 ("theta_e > theta_r", self.theta_e > self.theta_r), ("theta_r >= 0", self.theta_r >= 0),
+                                 ("thickness > 0", self.thickness > 0)) if not bool(ok.all())]
+        if bad:
+            raise LgarError("invalid soil parameters: need " + ", ".join(bad))
+        if not (float(dt_h) > 0 and int(num_subcycles) >= 1 and int(nint) >= 1 and float(initial_psi) > 0):
+            raise LgarError("need dt_h > 0, num_subcycles >= 1, nint >= 1, initial_psi > 0")
         self.L, self.N = L, N
         self.dims = _capi.LgarDims()
         d = self.dims

@@ -249,6 +249,10 @@ def test_bad_arguments_are_rejected():
     from lgar_py_amd import _capi
     with pytest.raises(lg.LgarError):
         lg.LgarEngine([1e-2] * 5, [1.5] * 5, [1.0] * 5, [0.4] * 5, [0.1] * 5, [10.0] * 5, n_columns=4)  # 5 layers: not compiled in
+    with pytest.raises(lg.LgarError, match="n > 1"):
+        lg.LgarEngine([1e-2] * 3, [1.0, 1.5, 1.5], [1.0] * 3, [0.4] * 3, [0.1] * 3, [10.0] * 3, n_columns=4)
+    with pytest.raises(lg.LgarError, match="theta_e > theta_r"):
+        lg.LgarEngine([1e-2] * 3, [1.5] * 3, [1.0] * 3, [0.4, 0.05, 0.4], [0.1] * 3, [10.0] * 3, n_columns=4)
     g = np.load(os.path.join(GOLDEN, "synth1_phil.npz"))
     eng = _engine(g, 4, torch.float64)
     with pytest.raises(lg.LgarError):
