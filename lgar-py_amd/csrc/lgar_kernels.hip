@@ -114,7 +114,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 // for the wave reductions) and store nothing.
 // BASIN = false is the lean variant (no epilogue code, tail lanes exit at once); BASIN = true adds the basin epilogue.
 template <typename R, int NL, int FMAX, bool BASIN>
-__global__ __launch_bounds__(WAVE, (sizeof(R) == 4) ? 3 : 1) void lgar_forward_kernel(KArgs<R> a) {
+__global__ __launch_bounds__(WAVE, (sizeof(R) == 4) ? 3 : 2) void lgar_forward_kernel(KArgs<R> a) {
   __shared__ WaveLDS<R, FMAX> lds;
   const int lane = threadIdx.x;
   const size_t N = (size_t)a.N;
