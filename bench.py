@@ -103,6 +103,9 @@ def main():
     ap.add_argument("--tile", type=int, default=1, help="time tiling of the 144-row synth_1 forcing")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="synth1", choices=["synth1", "phillipsburg"],
+                    help="synth1 (default): BASELINE configs[2]/[3]; phillipsburg: configs[1], replicated Phillipsburg "
+                         "column x 3000 hourly steps (use with --columns 10000 --dtype f64)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -139,14 +142,24 @@ def main():
     dtype = torch.float32 if args.dtype == "f32" else torch.float64
     elem = 4 if args.dtype == "f32" else 8
     N = args.columns
-    f = W.synth1_forcing(args.tile)
-    T = f.shape[0]
-    P = W.perturbed_columns(N, seed=rank)  # rank r holds columns [r*N, (r+1)*N) of the job; seed = shard index
-    sc = torch.tensor(W.forcing_scale(N, seed=1000 + rank), device=dev)
-    eng = lg.LgarEngine(P["alpha"], P["n"], P["ksat"], P["theta_e"], P["theta_r"], P["thickness"],
-                        dt_h=300.0 / 3600.0, ponded_depth_max=0.0, dtype=dtype, device=dev)
+    if args.workload == "phillipsburg":
+        g = np.load(os.path.join(ROOT, "tests", "golden", "phil_hourly_3000.npz"))  # first 3000 rows of the bundled forcing
+        f = g["forcing"]
+        T = f.shape[0]
+        P = {k: np.repeat(np.asarray(W.PHILLIPSBURG[k], dtype=np.float64)[:, None], N, 1) for k in
+             ("alpha", "n", "ksat", "theta_e", "theta_r", "thickness")}
+        sc = torch.ones(N, dtype=torch.float64, device=dev)
+        eng = lg.LgarEngine(P["alpha"], P["n"], P["ksat"], P["theta_e"], P["theta_r"], P["thickness"],
+                            dt_h=1.0, ponded_depth_max=2.0, dtype=dtype, device=dev)
+    else:
+        f = W.synth1_forcing(args.tile)
+        T = f.shape[0]
+        P = W.perturbed_columns(N, seed=rank)  # rank r holds columns [r*N, (r+1)*N) of the job; seed = shard index
+        sc = torch.tensor(W.forcing_scale(N, seed=1000 + rank), device=dev)
+        eng = lg.LgarEngine(P["alpha"], P["n"], P["ksat"], P["theta_e"], P["theta_r"], P["thickness"],
+                            dt_h=300.0 / 3600.0, ponded_depth_max=0.0, dtype=dtype, device=dev)
     precip = (torch.tensor(f[:, 0], device=dev)[:, None] * sc[None, :]).to(dtype).contiguous()
-    pet = torch.zeros_like(precip)
+    pet = (torch.tensor(f[:, 1], device=dev)[:, None] * torch.ones_like(sc)[None, :]).to(dtype).contiguous()
     # Keep the ensemble inside the reference's domain of validity (untimed set-up): a perturbed column whose
     # run makes the reference raise (status != 0, e.g. the negative-pow-base path of insert_water)
     # gets its soil re-drawn from the same distribution until no column faults.
@@ -208,10 +221,12 @@ def main():
             "metric": "column-timesteps/sec", "value": units / elapsed, "unit": "column-timesteps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(args.steps, 1),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]/[3]: %d synthetic columns per GPU (Phillipsburg P-1..3 soils "
-                                   "+-10%% per column, forcing_data_synth_1 shape x U(0.5,1.5) per column), 3 layers, %s, "
-                                   "T=%d steps of 300 s per pass; pass = set_internal_states + T x forward + basin-runoff "
-                                   "reduction" % (N, args.dtype, T),
+            "config": {"workload": ("BASELINE configs[2]/[3]: %d synthetic columns per GPU (Phillipsburg P-1..3 soils "
+                                    "+-10%% per column, forcing_data_synth_1 shape x U(0.5,1.5) per column), 3 layers, %s, "
+                                    "T=%d steps of 300 s per pass; pass = set_internal_states + T x forward + basin-runoff "
+                                    "reduction" % (N, args.dtype, T)) if args.workload == "synth1" else
+                                   ("BASELINE configs[1]: %d replicated Phillipsburg columns, 3 layers, %s, T=%d hourly steps "
+                                    "(bundled forcing, pdm 2 cm) per pass" % (N, args.dtype, T)),
                        "columns_per_gpu": N, "timesteps_per_pass": T, "columns_redrawn_to_stay_in_reference_domain": resampled, "parallelism": "columns sharded x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(N, T, args.dtype),
