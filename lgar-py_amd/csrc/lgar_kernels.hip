@@ -142,6 +142,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(R) == 4) ? 3 : 2) void lgar_forward_k
 #pragma unroll
   for (int i = 0; i < LGAR_GMAX; i++) col.giuh_q[i] = a.scalars[(3 + i) * N + c];
   col.status = a.status[c];
+  if (nf < NL) col.status |= LGAR_ST_STRUCT;  // not a state lgar_state_init / lgar_forward produced: column is skipped
   col.k_deepest = (nf > 0) ? a.k[(size_t)(nf - 1) * N + c] : R(0);
   col.new_front_frozen = false;
   col.drain();

@@ -263,6 +263,11 @@ def test_bad_arguments_are_rejected():
     C.memmove(C.byref(d), C.byref(eng.dims), C.sizeof(d))
     d.n_layers = 7
     assert lib.lgar_state_init(C.byref(d), C.byref(eng._params), C.byref(eng._state), eng.status.data_ptr(), 1, None) == -1
+    # a state the library did not produce (zero fronts) is rejected per column, not integrated
+    eng.n_fronts.zero_()
+    with pytest.raises(lg.LgarStatusError, match="structural"):
+        eng.forward(torch.zeros(2, 4), torch.zeros(2, 4))
+    eng.reset()
     # empty run is a no-op
     out = eng.forward(torch.zeros(0, 4), torch.zeros(0, 4))
     assert out["runoff"].shape == (0, 4)
