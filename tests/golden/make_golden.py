@@ -342,6 +342,9 @@ CASES["two_layer_phil_600"] = (run_case, dict(forcing=PH, soil=TWO, pdm=1.0, sub
 CASES["four_layer_synth1"] = (run_case, dict(forcing="forcing_data_synth_1.txt", soil=FOUR, pdm=0.0, subcycle_s=300, forcing_res_s=300, endtime_h=12.0))
 CASES["four_layer_phil_600"] = (run_case, dict(forcing=PH, soil=FOUR, pdm=2, subcycle_s=3600, forcing_res_s=3600, endtime_h=600.0))
 CASES["four_layer_synth0_600"] = (run_case, dict(forcing="forcing_data_synth_0.csv", soil=FOUR, pdm=0.0, subcycle_s=3600, forcing_res_s=3600, endtime_h=600.0))
+# more gradient fixtures (loss = mean(runoff^2), torch autograd through the reference)
+CASES["grad_synth0_60h"] = (run_case, dict(forcing="forcing_data_synth_0.csv", soil=PHIL, pdm=0.0, subcycle_s=3600, forcing_res_s=3600, endtime_h=60.0, grad=True))
+CASES["grad_four_layer_synth1"] = (run_case, dict(forcing="forcing_data_synth_1.txt", soil=FOUR, pdm=0.0, subcycle_s=300, forcing_res_s=300, endtime_h=12.0, grad=True))
 # closed-form capillary drive (lgar/green_ampt.py:85-98)
 CASES["closedG_synth1_phil"] = (run_case, dict(forcing="forcing_data_synth_1.txt", soil=PHIL, pdm=0.0, subcycle_s=300, forcing_res_s=300, endtime_h=12.0, closed_form=True))
 CASES["closedG_phil_hourly_600"] = (run_case, dict(forcing=PH, soil=PHIL, pdm=2, subcycle_s=3600, forcing_res_s=3600, endtime_h=600.0, closed_form=True))

@@ -25,7 +25,7 @@ def _setup(g, N, dtype=torch.float64, **kw):
     return P, pr, pe, ekw
 
 
-@pytest.mark.parametrize("name", ["grad_synth0_12h", "grad_synth1_phil"])
+@pytest.mark.parametrize("name", ["grad_synth0_12h", "grad_synth1_phil", "grad_synth0_60h", "grad_four_layer_synth1"])
 @pytest.mark.parametrize("mode", [1, 0], ids=["fast_search", "literal_search"])
 def test_gradients_match_reference_autograd(name, mode):
     from lgar_py_amd.autograd import lgar_series
