@@ -1,0 +1,37 @@
+"""CPU: bench.py's bookkeeping (algorithmic bytes of SURVEY §8d, committed-PMC lookups, CPU-baseline leg on a tiny sample)."""
+import importlib.util
+import os
+
+from conftest import ROOT
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_algorithmic_bytes_match_survey():
+    b = _bench()
+    # SURVEY §8d's formula B_alg = 4 s + (L 6 s + 2 F_MAX (5 s + 1) + 2 16 s) / T with L = 3, F_MAX = 16; the survey
+    # rounds B_col to 840 B (fp32) / 1648 B (fp64), the formula itself gives 872 / 1712
+    assert abs(b.alg_bytes_per_col_step(4, 144) - (16 + 872 / 144)) < 1e-12
+    assert abs(b.alg_bytes_per_col_step(4, 144) - 21.8) < 0.3 and abs(b.alg_bytes_per_col_step(4, 3000) - 16.3) < 0.05
+    assert abs(b.alg_bytes_per_col_step(8, 144) - (32 + 1712 / 144)) < 1e-12 and abs(b.alg_bytes_per_col_step(8, 144) - 43.4) < 0.6
+
+
+def test_committed_pmc_lookup():
+    b = _bench()
+    t = b.measured_traffic(1048576, 144, "f32")
+    assert t is not None and 1.5e9 < t < 3.4e9     # below the 3.33 GB algorithmic figure: no wasted re-reads
+    assert b.measured_traffic(12345, 144, "f32") is None
+    v = b.measured_valu(1048576, 144, "f32")
+    assert v is not None and 0.5 < v["busy_frac"] <= 1.0
+
+
+def test_cpu_baseline_leg_runs_on_a_tiny_sample(monkeypatch):
+    b = _bench()
+    monkeypatch.setenv("LGAR_CPU_THREADS", "2")
+    r = b.cpu_baseline(target_s=0.3)
+    assert r["kind"] == "port" and r["cores"] == 2 and r["value"] > 1e3 and "columns x 144 steps" in r["sample"]
