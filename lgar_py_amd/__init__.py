@@ -1,8 +1,8 @@
-"""Import alias for the package directory `lgar-py_amd/` (a hyphen cannot be imported directly)."""
-import os as _os
+"""lgar_py_amd: MI355X-native many-column LGAR infiltration engine (hot path of LGAR-py / dpLGAR).
 
-_real = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "lgar-py_amd")
-__path__[:] = [_real]
-_init = _os.path.join(_real, "__init__.py")
-with open(_init) as _f:
-    exec(compile(_f.read(), _init, "exec"))
+(`lgar-py_amd` at the repo root is a symlink to this directory: a hyphen cannot be imported.)
+"""
+from ._capi import ACC_NAMES, FMAX, LMAX, LgarError  # noqa: F401
+from .engine import LgarEngine, LgarStatusError, leaf_batch  # noqa: F401
+
+__all__ = ["LgarEngine", "LgarError", "LgarStatusError", "leaf_batch", "ACC_NAMES", "FMAX", "LMAX"]

@@ -62,8 +62,8 @@ def test_no_cpu_fallback():
 
 
 def test_product_never_imports_oracle():
-    """oracle/ is test infrastructure: nothing under lgar-py_amd/ may reference it."""
-    pk = os.path.join(ROOT, "lgar-py_amd")
+    """oracle/ is test infrastructure: nothing under lgar_py_amd/ may reference it."""
+    pk = os.path.join(ROOT, "lgar_py_amd")
     for dp, _, fs in os.walk(pk):
         for f in fs:
             if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
