@@ -11,19 +11,20 @@ Inputs are resident in HBM before the timed region.  Weak scaling: columns per G
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0.
+Without a launcher (`WORLD_SIZE` unset) and N > 1 the script starts its own N ranks, one fresh child process per GPU,
+BEFORE anything in this process touches the GPU.  Prints ONE JSON line on rank 0.
+LGAR_DIST_BACKEND=gloo is a rehearsal mode: the ranks may share GPUs and the [T] reduction goes through the host.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-import numpy as np
-import torch
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
@@ -34,36 +35,50 @@ def alg_bytes_per_col_step(elem, T, L=3, fmax=16):
     return 4 * elem + b_col / T
 
 
-def measured_traffic(N, T, dtype):
-    """HBM bytes per launch from the committed PMC passes (profiles/*/traffic.json), when they were taken on exactly
-    this workload; FETCH_SIZE corrected x2 as MI355X_MICROARCH.md prescribes for gfx950.  None otherwise."""
-    best = None
+def _profile_records():
     pdir = os.path.join(ROOT, "profiles")
     for r in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
         f = os.path.join(pdir, r, "traffic.json")
         if os.path.exists(f):
-            t = json.load(open(f))
-            if (t.get("columns"), t.get("timesteps"), t.get("dtype")) == (N, T, dtype):
-                best = (2 * t["FETCH_SIZE_KB"] + t["WRITE_SIZE_KB"]) * 1024
+            with open(f) as fh:
+                yield r, json.load(fh)
+
+
+def measured_traffic(N, T, dtype):
+    """HBM bytes per launch from the committed PMC passes (profiles/*/traffic.json, latest round wins), when they were
+    taken on exactly this workload; FETCH_SIZE corrected x2 as MI355X_MICROARCH.md prescribes for gfx950."""
+    best = None
+    for _, t in _profile_records():
+        if (t.get("columns"), t.get("timesteps"), t.get("dtype")) == (N, T, dtype):
+            best = (2 * t["FETCH_SIZE_KB"] + t["WRITE_SIZE_KB"]) * 1024
     return best
 
 
 def measured_valu(N, T, dtype):
-    """Compute-side roof from the committed PMC passes (profiles/*/traffic.json 'valu' block), same workload only."""
+    """Compute-side counters from the committed PMC passes (profiles/*/traffic.json 'valu' block), same workload only."""
     best = None
-    pdir = os.path.join(ROOT, "profiles")
-    for r in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
-        f = os.path.join(pdir, r, "traffic.json")
-        if os.path.exists(f):
-            t = json.load(open(f))
-            if (t.get("columns"), t.get("timesteps"), t.get("dtype")) == (N, T, dtype) and "valu" in t:
-                best = t["valu"]
+    for r, t in _profile_records():
+        if (t.get("columns"), t.get("timesteps"), t.get("dtype")) == (N, T, dtype) and "valu" in t:
+            best = dict(t["valu"], source="profiles/%s/traffic.json" % r)
     return best
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(target_s=12.0):
-    """Oracle (C restatement, fp64, OpenMP over columns) timed on this host on a bounded sample of the
-    same workload.  A reported baseline, never the thing measured above."""
+    """Oracle (C restatement, fp64) timed on this host on a bounded sample of the same workload: all host cores of this
+    box's CPU share (OpenMP over columns) and one thread.  A reported baseline, never the thing measured above."""
+    import numpy as np
+
     from lgar_py_amd import workloads as W
     from oracle import lgar_oracle as O
 
@@ -73,28 +88,35 @@ def cpu_baseline(target_s=12.0):
     f = W.synth1_forcing()
     T = f.shape[0]
 
-    def run(n):
+    def run(n, threads):
         P = W.perturbed_columns(n, seed=0)
         sc = W.forcing_scale(n, seed=1)
         pr = f[:, 0:1] * sc[None, :]
         pe = np.zeros_like(pr)
         t0 = time.perf_counter()
         O.run_columns(P["alpha"], P["n"], P["ksat"], P["theta_e"], P["theta_r"], P["thickness"], pr, pe,
-                      pdm=0.0, dt_h=300.0 / 3600.0, nthreads=cores, want_series=False)
+                      pdm=0.0, dt_h=300.0 / 3600.0, nthreads=threads, want_series=False)
         return time.perf_counter() - t0
 
-    n0 = 64 * cores
-    t = run(n0)
-    n = int(max(n0, min(n0 * target_s / max(t, 1e-3), 2_000_000)))
-    n = (n // 64) * 64
-    t = run(n)
+    def sized(threads, budget):
+        n0 = 64 * threads
+        t = run(n0, threads)
+        n = int(max(n0, min(n0 * budget / max(t, 1e-3), 2_000_000)))
+        n = max(64, (n // 64) * 64)
+        return n, run(n, threads)
+
+    n, t = sized(cores, target_s * 0.7)
+    n1, t1 = sized(1, target_s * 0.3)
     return {"value": n * T / t, "unit": "column-timesteps/s", "cores": cores, "kind": "port",
             "sample": "%d columns x %d steps of the same synth_1 workload, fp64 C oracle, OpenMP, %.1f s" % (n, T, t),
+            "single_thread": {"value": n1 * T / t1, "cores": 1,
+                              "sample": "%d columns x %d steps, 1 thread, %.1f s" % (n1, T, t1)},
+            "cpu_model": cpu_model(), "host_cores_visible": avail,
             "reference_pytorch_cpu_loop": "10.9 column-timesteps/s on this forcing shape, 1 core (BASELINE.md section 2: observed "
                                           "in the survey container; the Python reference cannot travel to the GPU box)"}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -103,15 +125,84 @@ def main():
     ap.add_argument("--tile", type=int, default=1, help="time tiling of the 144-row synth_1 forcing")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the fp64 / configs[1] sub-records and the VALU probe")
     ap.add_argument("--workload", default="synth1", choices=["synth1", "phillipsburg"],
                     help="synth1 (default): BASELINE configs[2]/[3]; phillipsburg: configs[1], replicated Phillipsburg "
                          "column x 3000 hourly steps (use with --columns 10000 --dtype f64)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(args):
+    """No launcher: start --gpus fresh child interpreters, one rank per GPU (this process has not touched the GPU and
+    never will: it only waits).  Rank 0's stdout carries the JSON line."""
+    port = int(os.environ.get("MASTER_PORT", 0)) or _free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get(
+                       "HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out0 or "")
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        raise SystemExit("bench.py: ranks failed: %s" % bad)
+
+
+def valu_probe_record(dev):
+    """Live compute-side roof on this chip: peak wave-instructions/s of v_exp_f32 / v_log_f32 / v_fma_f32 and of the
+    Geff loop's own instruction mix (csrc/lgar_probe.hip), best over 2-4 resident waves per SIMD."""
+    import ctypes as C
+
+    import torch
+
+    from lgar_py_amd import _capi
+    lib = _capi.load()
+    ops = {"v_exp_f32": 0, "v_log_f32": 1, "v_fma_f32": 4, "geff_mix": 16}
+    rec = {}
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+    for nm, op in ops.items():
+        best = 0.0
+        for w in (2, 4):
+            lds = ((160 * 1024) // (4 * w) // 256) * 256
+            nwg, iters = n_cu * 4 * w * 2, 1500
+            sink = torch.zeros(nwg * 64, dtype=torch.float32, device=dev)
+            for _ in range(2):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                rc = lib.lgar_valu_probe(op, nwg, lds, iters, sink.data_ptr(), st)
+                b.record()
+                torch.cuda.synchronize(dev)
+                if rc == 0:
+                    best = max(best, nwg * iters * 64 / (a.elapsed_time(b) * 1e-3))
+        rec[nm] = best
+    return rec
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args)
+
+    import numpy as np
+    import torch
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the LGAR engine has no CPU fallback")
@@ -122,7 +213,10 @@ def main():
 
     # one process per GPU; LGAR_DIST_BACKEND=gloo is a rehearsal mode (several ranks may then share one GPU)
     backend = os.environ.get("LGAR_DIST_BACKEND", "nccl")
-    dev = torch.device("cuda", local_rank % torch.cuda.device_count())
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and world > ndev:
+        raise SystemExit("--gpus %d but only %d visible (LGAR_DIST_BACKEND=gloo rehearses more ranks than GPUs)" % (world, ndev))
+    dev = torch.device("cuda", local_rank % ndev)
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -142,38 +236,43 @@ def main():
     dtype = torch.float32 if args.dtype == "f32" else torch.float64
     elem = 4 if args.dtype == "f32" else 8
     N = args.columns
-    if args.workload == "phillipsburg":
-        g = np.load(os.path.join(ROOT, "tests", "golden", "phil_hourly_3000.npz"))  # first 3000 rows of the bundled forcing
-        f = g["forcing"]
-        T = f.shape[0]
-        P = {k: np.repeat(np.asarray(W.PHILLIPSBURG[k], dtype=np.float64)[:, None], N, 1) for k in
-             ("alpha", "n", "ksat", "theta_e", "theta_r", "thickness")}
-        sc = torch.ones(N, dtype=torch.float64, device=dev)
-        eng = lg.LgarEngine(P["alpha"], P["n"], P["ksat"], P["theta_e"], P["theta_r"], P["thickness"],
-                            dt_h=1.0, ponded_depth_max=2.0, dtype=dtype, device=dev)
-    else:
-        f = W.synth1_forcing(args.tile)
-        T = f.shape[0]
-        P = W.perturbed_columns(N, seed=rank)  # rank r holds columns [r*N, (r+1)*N) of the job; seed = shard index
-        sc = torch.tensor(W.forcing_scale(N, seed=1000 + rank), device=dev)
-        eng = lg.LgarEngine(P["alpha"], P["n"], P["ksat"], P["theta_e"], P["theta_r"], P["thickness"],
-                            dt_h=300.0 / 3600.0, ponded_depth_max=0.0, dtype=dtype, device=dev)
-    precip = (torch.tensor(f[:, 0], device=dev)[:, None] * sc[None, :]).to(dtype).contiguous()
-    pet = (torch.tensor(f[:, 1], device=dev)[:, None] * torch.ones_like(sc)[None, :]).to(dtype).contiguous()
-    # Keep the ensemble inside the reference's domain of validity (untimed set-up): a perturbed column whose
-    # run makes the reference raise (status != 0, e.g. the negative-pow-base path of insert_water)
-    # gets its soil re-drawn from the same distribution until no column faults.
-    resampled = 0
-    for it in range(1, 16):
-        eng.reset()
-        eng.forward(precip, pet, series=(), check=False)
-        bad = torch.nonzero(eng.status != 0).flatten()
-        if bad.numel() == 0:
-            break
-        resampled += int(bad.numel())
-        Q = W.perturbed_columns(int(bad.numel()), seed=(rank + 1) * 100003 + it)
-        for k, t in (("alpha", eng.alpha), ("n", eng.n), ("ksat", eng.ksat), ("theta_e", eng.theta_e), ("theta_r", eng.theta_r)):
-            t[:, bad] = torch.tensor(Q[k], device=dev).to(dtype)
+
+    def make_workload(kind, n_cols, dt, seed_rank):
+        """(engine, precip[T, N], pet[T, N], redrawn) with inputs resident in HBM."""
+        if kind == "phillipsburg":
+            g = np.load(os.path.join(ROOT, "tests", "golden", "phil_hourly_3000.npz"))  # first 3000 rows of the bundled forcing
+            f = g["forcing"]
+            P = {k: np.repeat(np.asarray(W.PHILLIPSBURG[k], dtype=np.float64)[:, None], n_cols, 1) for k in
+                 ("alpha", "n", "ksat", "theta_e", "theta_r", "thickness")}
+            sc = torch.ones(n_cols, dtype=torch.float64, device=dev)
+            eng = lg.LgarEngine(P["alpha"], P["n"], P["ksat"], P["theta_e"], P["theta_r"], P["thickness"],
+                                dt_h=1.0, ponded_depth_max=2.0, dtype=dt, device=dev)
+        else:
+            f = W.synth1_forcing(args.tile)
+            P = W.perturbed_columns(n_cols, seed=seed_rank)  # rank r holds columns [r*N, (r+1)*N) of the job; seed = shard index
+            sc = torch.tensor(W.forcing_scale(n_cols, seed=1000 + seed_rank), device=dev)
+            eng = lg.LgarEngine(P["alpha"], P["n"], P["ksat"], P["theta_e"], P["theta_r"], P["thickness"],
+                                dt_h=300.0 / 3600.0, ponded_depth_max=0.0, dtype=dt, device=dev)
+        pr = (torch.tensor(f[:, 0], device=dev)[:, None] * sc[None, :]).to(dt).contiguous()
+        pe = (torch.tensor(f[:, 1], device=dev)[:, None] * torch.ones_like(sc)[None, :]).to(dt).contiguous()
+        # Keep the ensemble inside the reference's domain of validity (untimed set-up): a perturbed column whose
+        # run makes the reference raise (status != 0, e.g. the negative-pow-base path of insert_water, DESIGN.md)
+        # gets its soil re-drawn from the same distribution until no column faults.
+        redrawn = 0
+        for it in range(1, 16):
+            eng.reset()
+            eng.forward(pr, pe, series=(), check=False)
+            bad = torch.nonzero(eng.status != 0).flatten()
+            if bad.numel() == 0 or kind == "phillipsburg":
+                break
+            redrawn += int(bad.numel())
+            Q = W.perturbed_columns(int(bad.numel()), seed=(seed_rank + 1) * 100003 + it)
+            for k, t in (("alpha", eng.alpha), ("n", eng.n), ("ksat", eng.ksat), ("theta_e", eng.theta_e), ("theta_r", eng.theta_r)):
+                t[:, bad] = torch.tensor(Q[k], device=dev).to(dt)
+        return eng, pr, pe, redrawn
+
+    eng, precip, pet, resampled = make_workload(args.workload, N, dtype, rank)
+    T = precip.shape[0]
     out = {"runoff": torch.empty(T, N, dtype=dtype, device=dev), "percolation": torch.empty(T, N, dtype=dtype, device=dev)}
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
@@ -212,11 +311,13 @@ def main():
     faulted = torch.tensor([int((eng.status != 0).sum().item())], device=dev)
     if world > 1:
         all_reduce(faulted)
+    geff_waves = eng.geff_wave_calls() if hasattr(eng, "geff_wave_calls") else None
 
     if rank == 0:
         units = N * world * T * args.steps
         b_alg = alg_bytes_per_col_step(elem, T)
         achieved = b_alg * N * T / (kern_ms * 1e-3) / 1e9
+        kname = "lgar_forward_kernel<%s,3,%d>" % ("float" if elem == 4 else "double", lg._capi.FMAX)
         line = {
             "metric": "column-timesteps/sec", "value": units / elapsed, "unit": "column-timesteps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(args.steps, 1),
@@ -227,19 +328,79 @@ def main():
                                     "reduction" % (N, args.dtype, T)) if args.workload == "synth1" else
                                    ("BASELINE configs[1]: %d replicated Phillipsburg columns, 3 layers, %s, T=%d hourly steps "
                                     "(bundled forcing, pdm 2 cm) per pass" % (N, args.dtype, T)),
-                       "columns_per_gpu": N, "timesteps_per_pass": T, "columns_redrawn_to_stay_in_reference_domain": resampled, "parallelism": "columns sharded x%d" % world},
+                       "columns_per_gpu": N, "timesteps_per_pass": T, "columns_redrawn_to_stay_in_reference_domain": resampled,
+                       "parallelism": "columns sharded x%d" % world,
+                       "collective": None if world == 1 else ("%s all-reduce of basin runoff [T]" % backend)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(N, T, args.dtype),
-                         "traffic_note": "bytes per launch from separate rocprofv3 --pmc passes (profiles/r01/traffic.json), not live",
+                         "traffic_note": "bytes per launch from separate rocprofv3 --pmc passes (profiles/*/traffic.json), not live",
                          "algorithmic_bytes_per_launch": b_alg * N * T,
-                         "kernel": "lgar_forward_kernel<%s,3,12>" % ("float" if elem == 4 else "double"),
-                         "kernel_ms": kern_ms, "alg_bytes_per_column_timestep": b_alg,
+                         "kernel": kname, "kernel_ms": kern_ms, "alg_bytes_per_column_timestep": b_alg,
                          "note": "path is VALU bound, not HBM bound (~1e3 flop/B; see valu_roofline and DESIGN.md); "
-                                 "alg bytes use SURVEY 8(d)'s figure (F_MAX=16 state); the kernel's own state is F_MAX=12"},
-            "valu_roofline": measured_valu(N, T, args.dtype),
+                                 "alg bytes use SURVEY 8(d)'s figure (F_MAX=16 state)"},
             "faulted_columns": int(faulted.item()),
             "basin_runoff_total_cm": float(basin.sum().item()),
         }
+        pmc = measured_valu(N, T, args.dtype)
+        if world == 1 and not args.no_extras:
+            # compute-side roof, live: what this chip's vector ALU sustains vs what the Geff trapezoid (the dominant
+            # instruction stream: 5 v_log/v_exp per node, 121 nodes per call) got out of it
+            probe = valu_probe_record(dev)
+            vr = {"bound": "valu-issue", "unit": "wave-instructions/s",
+                  "peak_v_exp_f32": probe["v_exp_f32"], "peak_v_log_f32": probe["v_log_f32"],
+                  "peak_v_fma_f32": probe["v_fma_f32"], "peak_geff_mix": probe["geff_mix"],
+                  "definition": "peaks measured live by lgar_valu_probe (64-instruction unrolled inline-asm loops, best of 2 "
+                                "and 4 waves/SIMD); geff_mix = the packed Geff loop's own mix (per 64: 8 v_log, 12 v_exp, 24 "
+                                "packed, 20 plain)"}
+            if geff_waves is not None:
+                nint = 120
+                trans = geff_waves * (nint * 5 + 12)  # wave-instructions: 5 per node + the 4 pows / 2 sqrt-free K of the end points
+                vr["geff_wave_calls_per_launch"] = geff_waves
+                vr["achieved_geff_transcendentals"] = trans / (kern_ms * 1e-3)
+                peak_t = 0.5 * (probe["v_exp_f32"] + probe["v_log_f32"])
+                vr["frac_of_transcendental_peak"] = trans / (kern_ms * 1e-3) / peak_t if peak_t else None
+                mix_insts = geff_waves * (nint / 2) * 32  # the loop body: 32 instructions per node pair
+                vr["frac_of_geff_mix_peak"] = mix_insts / (kern_ms * 1e-3) / probe["geff_mix"] if probe["geff_mix"] else None
+            if pmc:
+                vr["pmc"] = pmc
+            line["valu_roofline"] = vr
+        elif pmc:
+            line["valu_roofline"] = pmc
+        if world == 1 and not args.no_extras and args.workload == "synth1":
+            subs = {}
+            # the parity-bearing precision on the same workload (1e-6 vs the reference holds in fp64)
+            if args.dtype == "f32":
+                e64, p64, q64, _ = make_workload("synth1", N, torch.float64, rank)
+                ms = []
+                for _ in range(3):
+                    e64.reset()
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record()
+                    e64.forward(p64, q64, series=("runoff", "percolation"), basin=("runoff",), check=False)
+                    b.record()
+                    torch.cuda.synchronize()
+                    ms.append(a.elapsed_time(b))
+                ms = min(ms[1:])
+                subs["fp64"] = {"value": N * T / (ms * 1e-3), "unit": "column-timesteps/s", "kernel_ms": ms, "columns": N,
+                                "timesteps": T, "dtype": "f64", "workload": "same synth_1 ensemble, fp64 (parity precision)",
+                                "roofline_frac_hbm": alg_bytes_per_col_step(8, T) * N * T / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                del e64, p64, q64
+            ec, pc, qc, _ = make_workload("phillipsburg", 10_000, torch.float64, 0)
+            Tc = pc.shape[0]
+            ms = []
+            for _ in range(2):
+                ec.reset()
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                ec.forward(pc, qc, series=("runoff", "percolation"), check=False)
+                b.record()
+                torch.cuda.synchronize()
+                ms.append(a.elapsed_time(b))
+            subs["configs1"] = {"value": 10_000 * Tc / (min(ms) * 1e-3), "unit": "column-timesteps/s", "kernel_ms": min(ms),
+                                "columns": 10_000, "timesteps": Tc, "dtype": "f64",
+                                "workload": "BASELINE configs[1]: 10k replicated Phillipsburg columns x 3000 hourly steps, fp64 "
+                                            "(157 waves on 1024 SIMDs: latency-bound, not a throughput figure)"}
+            line["sub_records"] = subs
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

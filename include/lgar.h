@@ -28,7 +28,9 @@
 extern "C" {
 #endif
 
+#ifndef LGAR_FMAX
 #define LGAR_FMAX 12  /* front slots per column (reference lists are unbounded, observed <= 8; overflow -> status bit) */
+#endif
 #define LGAR_LMIN 2   /* the reference itself needs >= 2 layers (Layer.py:204) */
 #define LGAR_LMAX 4   /* soil layers: kernels are compiled for 2, 3 and 4 (BASELINE configs: 3) */
 #define LGAR_GMAX 8   /* GIUH ordinates */
@@ -155,6 +157,39 @@ int32_t lgar_forward_tangent(const LgarDims *dims, const LgarParams *params, con
 int32_t lgar_leaf_batch(int32_t op, int32_t n_items, const void *x, const void *y, double z, const void *alpha,
                         const void *n, const void *ksat, const void *theta_e, const void *theta_r, int32_t nint,
                         double wilting_point_psi, void *out, int32_t dtype, void *stream);
+
+/* Measurement only (no reference counterpart): vector-ALU issue-rate probe, the compute-side roof bench.py prices the
+ * path against (the path is VALU-bound: ~10^3 flop per algorithmic byte).  Launches n_workgroups one-wave workgroups,
+ * each running `iters` iterations of 64 instructions of kind `op`; lds_bytes_per_workgroup sets the resident waves
+ * per SIMD (160 KiB / (4 k) => k).  sink: device float[n_workgroups * 64] (never written in practice).  The caller
+ * times the launch on `stream`. */
+#define LGAR_PROBE_EXP 0      /* v_exp_f32, 8 independent chains */
+#define LGAR_PROBE_LOG 1      /* v_log_f32 */
+#define LGAR_PROBE_RCP 2      /* v_rcp_f32 */
+#define LGAR_PROBE_SQRT 3     /* v_sqrt_f32 */
+#define LGAR_PROBE_FMA 4      /* v_fma_f32 */
+#define LGAR_PROBE_MUL 5      /* v_mul_f32 */
+#define LGAR_PROBE_PK_FMA 6   /* v_pk_fma_f32 */
+#define LGAR_PROBE_PK_MUL 7   /* v_pk_mul_f32 */
+#define LGAR_PROBE_CNDMASK 8  /* v_cndmask_b32 */
+#define LGAR_PROBE_CMP 9      /* v_cmp_lt_f32 */
+#define LGAR_PROBE_EXP_DEP 10 /* v_exp_f32, ONE dependent chain (latency) */
+#define LGAR_PROBE_FMA_DEP 11 /* v_fma_f32, ONE dependent chain */
+#define LGAR_PROBE_FMA64 12   /* v_fma_f64 */
+#define LGAR_PROBE_MUL64 13   /* v_mul_f64 */
+#define LGAR_PROBE_ADD64 14   /* v_add_f64 */
+#define LGAR_PROBE_RCP64 15   /* v_rcp_f64 */
+#define LGAR_PROBE_GEFF_MIX 16 /* the instruction mix of the packed fp32 Geff loop: per 64: 8 v_log, 12 v_exp, 24 packed, 20 plain */
+#define LGAR_PROBE_CNDMASK_SGPR 17 /* v_cndmask_b32 with an SGPR-pair mask */
+#define LGAR_PROBE_BFI 18      /* v_bfi_b32 (bitwise select on a vector mask) */
+#define LGAR_PROBE_CMP_CNDMASK 19 /* v_cmp_lt_f32 + v_cndmask_b32 pairs */
+#define LGAR_PROBE_ADD 20      /* v_add_f32 */
+#define LGAR_PROBE_READLANE 21 /* v_readlane_b32 (what an SGPR spill reload costs) */
+#define LGAR_PROBE_DS_READ 22  /* ds_read_b32, lane-contiguous */
+#define LGAR_PROBE_MIN 23      /* v_min_f32 */
+#define LGAR_PROBE_INSTS_PER_ITER 64
+int32_t lgar_valu_probe(int32_t op, int32_t n_workgroups, int32_t lds_bytes_per_workgroup, int32_t iters, void *sink,
+                        void *stream);
 
 #ifdef __cplusplus
 }

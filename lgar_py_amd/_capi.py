@@ -18,7 +18,7 @@ ST_NAN, ST_NEGBASE, ST_THETA_ORDER, ST_OVERFLOW, ST_ITERCAP, ST_BOTTOM, ST_STRUC
 STATUS_NAMES = {1: "NaN", 2: "negative pow base", 4: "theta order", 8: "front overflow", 16: "iteration cap",
                 32: "front reached domain bottom", 64: "structural error"}
 EXPORTS = ["lgar_version", "lgar_fmax", "lgar_lmax", "lgar_state_init", "lgar_forward", "lgar_forward_tangent",
-           "lgar_leaf_batch"]
+           "lgar_leaf_batch", "lgar_valu_probe"]
 
 
 class LgarDims(C.Structure):
@@ -82,11 +82,17 @@ def load():
     lib.lgar_state_init.argtypes = [p(LgarDims), p(LgarParams), p(LgarState), vp, i32, vp]
     lib.lgar_forward.restype = i32
     lib.lgar_forward.argtypes = [p(LgarDims), p(LgarParams), p(LgarState), p(LgarForcing), p(LgarStepOut), vp, i32, vp]
-    lib.lgar_forward_tangent.restype = i32
-    lib.lgar_forward_tangent.argtypes = [p(LgarDims), p(LgarParams), p(LgarParams), p(LgarForcing), vp, vp, vp, vp, vp,
-                                         i32, vp]
+    if hasattr(lib, "lgar_forward_tangent") or not os.environ.get("LGAR_LIB"):  # measurement variants omit it
+        lib.lgar_forward_tangent.restype = i32
+        lib.lgar_forward_tangent.argtypes = [p(LgarDims), p(LgarParams), p(LgarParams), p(LgarForcing), vp, vp, vp, vp, vp,
+                                             i32, vp]
     lib.lgar_leaf_batch.restype = i32
     lib.lgar_leaf_batch.argtypes = [i32, i32, vp, vp, dbl, vp, vp, vp, vp, vp, i32, dbl, vp, i32, vp]
+    lib.lgar_valu_probe.restype = i32
+    lib.lgar_valu_probe.argtypes = [i32, i32, i32, i32, vp, vp]
+    global FMAX
+    if os.environ.get("LGAR_LIB"):
+        FMAX = lib.lgar_fmax()  # measurement variants (tools/ablate.py) may be built with another front capacity
     if lib.lgar_fmax() != FMAX or lib.lgar_lmax() != LMAX:
         raise LgarError("liblgar_hip.so was built with different LGAR_FMAX/LGAR_LMAX than the Python binding")
     _lib = lib

@@ -6,7 +6,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.environ.get("LGAR_LIB") or os.path.join(CSRC, "liblgar_hip.so")
-SOURCES = ["lgar_kernels.hip", "lgar_tangent.hip"]
+SOURCES = ["lgar_kernels.hip", "lgar_tangent.hip", "lgar_probe.hip"]
 HEADERS = ["lgar_device.hpp", "lgar_dual.hpp", "lgar_math.hpp", "lgar_host.hpp", os.path.join("..", "..", "include", "lgar.h")]
 # -ffp-contract=off: expression rounding follows the reference's Python (no FMA contraction)
 # fp32 division stays correctly rounded: with the rcp-based fast divide x/x != 1, Se = (theta-theta_r)/(theta_e-theta_r)
@@ -24,6 +24,34 @@ def _stale():
         if os.path.exists(fp) and os.path.getmtime(fp) > t:
             return True
     return False
+
+
+def build_variant(name, extra_flags, verbose=False):
+    """Measurement variants (tools/ablate.py): the same sources with extra -D flags -> csrc/variants/liblgar_hip_<name>.so
+    (select one at run time with LGAR_LIB=<path>)."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    vdir = os.path.join(CSRC, "variants")
+    os.makedirs(vdir, exist_ok=True)
+    out = os.path.join(vdir, "liblgar_hip_%s.so" % name)
+    srcs = [os.path.join(CSRC, f) for f in SOURCES if f != "lgar_tangent.hip"]  # forward path only
+    if os.path.exists(out) and all(os.path.getmtime(os.path.join(CSRC, f)) <= os.path.getmtime(out) for f in SOURCES + HEADERS):
+        return out
+    cflags = [f for f in FLAGS if f != "-shared"] + list(extra_flags)
+    objs, procs = [], []
+    for src in srcs:
+        obj = os.path.join(vdir, os.path.basename(src)[:-4] + "_%s.o" % name)
+        cmd = [hipcc] + cflags + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd)))
+        objs.append(obj)
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out])
+    for o in objs:
+        os.remove(o)
+    return out
 
 
 def build(force=False, verbose=False):

@@ -55,6 +55,12 @@ __device__ __forceinline__ float mn(float a, float b) { return fminf(a, b); }
 __device__ __forceinline__ bool is_nan(double x) { return x != x; }
 __device__ __forceinline__ bool is_nan(float x) { return x != x; }
 
+// Cost attribution by duplication (tools/ablate.py builds variants with -DLGAR_DUP_<X>): the named routine runs twice
+// on opaque copies of its inputs, results unchanged, so the time difference to the plain build is that routine's cost
+// with the column dynamics (and therefore all other work) untouched.
+__device__ __forceinline__ float opaque(float x) { asm volatile("" : "+v"(x)); return x; }
+__device__ __forceinline__ double opaque(double x) { asm volatile("" : "+v"(x)); return x; }
+
 // tolerances: the reference's absolute 1e-12 (layers/Layer.py:60) is unreachable in fp32
 template <typename R> struct Tol;
 template <> struct Tol<double> {
@@ -198,17 +204,18 @@ template <typename S> __device__ __forceinline__ S geff_fused(const LayerK<S> &l
   const S hdh = dh / R(2.0);
   const S k_sat1 = k_from_se(l, S(R(1.0)));  // K at Se == 1 (|h| < 0.1)
   const S half_m = R(-0.5) * l.m;
+  const S nm1 = l.n - R(1.0);  // n m = n - 1: a^m = (alpha h)^(n-1)
   S g = S(R(0.0));
   S k1 = k_from_se(l, se_i);
   S h2 = h_i + dh;
   for (int i = 0; i < nint; i++) {
     if (sizeof(R) == 4) h2 = (i + 1 >= nint) ? h_f : h_i + R(i + 1) * dh;
-    const S lg = lg2(l.alpha * h2);
-    const S a = ex2(l.n * lg);
-    const S l1 = lg2(R(1.0) + a);
+    // four transcendentals per node: P = a^m = x^(n-1), a = x P, sqrt(Se) = (1+a)^(-m/2), (a/(1+a))^m = P Se
+    const S x = l.alpha * h2;
+    const S P = ex2(nm1 * lg2(x));
+    const S l1 = lg2(R(1.0) + x * P);
     const S sqrt_se = ex2(half_m * l1);
-    const S op = ex2(l.m * (l.n * lg - l1));
-    const S t = R(1.0) - op;
+    const S t = R(1.0) - P * (sqrt_se * sqrt_se);
     S k2 = l.ksat * sqrt_se * (t * t);
     k2 = (ab(val(h2)) < R(0.1) || val(h2) < R(0.0)) ? k_sat1 : k2;
     g = g + ((k1 + k2) * hdh);
@@ -217,60 +224,80 @@ template <typename S> __device__ __forceinline__ S geff_fused(const LayerK<S> &l
   }
   return ab(g / l.ksat);
 }
-// fp32: two nodes per iteration on packed registers, so the non-transcendental half of the node arithmetic
-// issues as v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 (two lanes' worth of flops per instruction)
-#ifndef LGAR_NO_PACKED_GEFF
+// fp32 Geff, lean form (what bench.py measures).  Per node, with x = alpha h and K_r = K / Ksat (Ksat cancels in
+// G = |integral of K dh| / Ksat):
+//     lg = log2 x;  P = 2^((n-1) lg) = x^(n-1) = a^m   [a = x^n, n m = n - 1];   a = x P;
+//     l1 = log2(1 + a);  s = 2^(-m/2 l1) = sqrt(Se);  K_r = s (1 - P s^2)^2        [(a/(1+a))^m = a^m Se]
+// i.e. FOUR transcendentals per node (v_log, v_exp, v_log, v_exp) instead of five, and no division.  The vector ALU
+// issues a transcendental in 8 cycles, a packed op in 4 and a v_cndmask_b32 in 16 (measured, tools/valu_probe.py), so
+// the loop is laid out to be select-free: the |h| < 0.1 -> Se = 1 rule (utils.py:124-128) can only bind on a SUFFIX of
+// the nodes (h falls monotonically from h_i to h_f), so a wave-uniform count of leading node pairs that no lane needs
+// to test runs in a select-free loop, the rest in a checked loop.  The trapezoid is summed as
+// dh/2 (K_0 + K_n + 2 sum of interior nodes): one packed add per node pair.  Interior nodes sit at h_i + j dh (no running
+// sum: it drifts by cm for very dry soil); the last node is h_f itself, which dominates the integral for dry soil.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+#ifndef LGAR_NO_PACKED_GEFF
 template <> __device__ __forceinline__ float geff<float>(const LayerK<float> &l, float theta1, float theta2, int nint) {
   const float se_i = se_from_theta(l, theta1);
   const float se_f = se_from_theta(l, theta2);
   const float h_i = h_from_se(l, se_i);
   const float h_f = h_from_se(l, se_f);
   const float dh = (h_f - h_i) / float(nint);
-  const float hdh = dh / 2.0f;
-  const float k_sat1 = k_from_se(l, 1.0f);
-  const float half_m = -0.5f * l.m;
-  float g = 0.0f;
-  float k1 = k_from_se(l, se_i);
-  int i = 0;
-  for (; i + 1 < nint; i += 2) {
-    f32x2 h2;
-    h2.x = h_i + float(i + 1) * dh;
-    h2.y = (i + 2 >= nint) ? h_f : h_i + float(i + 2) * dh;
-    const f32x2 x = l.alpha * h2;
-    f32x2 lg;
+  const float nm1 = l.n - 1.0f;
+  const float hm = -0.5f * l.m;
+  const float x0 = l.alpha * h_i, dx = l.alpha * dh, xcut = 0.1f * l.alpha;
+  // K_r at Se == 1 (calc_k_from_se's 1e-12 nudge, utils.py:147-150): (1 - (1e-12)^m)^2
+  const float tsat = 1.0f - ex2(l.m * -39.863137f);
+  const float ksat1 = tsat * tsat;
+  auto node = [&](float x) {
+    const float lg = lg2(x);
+    const float P = ex2(nm1 * lg);
+    const float l1 = lg2(__builtin_fmaf(x, P, 1.0f));
+    const float sr = ex2(hm * l1);
+    const float t = __builtin_fmaf(-P, sr * sr, 1.0f);
+    const float k = sr * (t * t);
+    return (x < xcut) ? ksat1 : k;
+  };
+  const int M = nint - 1;       // interior nodes j = 1 .. nint-1
+  const int pairs = M >> 1;
+  // leading interior nodes with h >= 0.1 for certain: j < (x0 - xcut) / -dx (one node of margin for rounding)
+  const float jf = (x0 - xcut) / -dx - 1.0f;
+  int safe = (jf > 0.0f) ? ((jf < float(M)) ? int(jf) : M) : 0;  // NaN (dx == 0) -> 0
+  safe >>= 1;
+  int safe_pairs = 0;  // wave-uniform minimum by bisection on ballots (plain compares + scalar ops)
+  for (int bit = 64; bit; bit >>= 1) {
+    const int cand = safe_pairs + bit;
+    if (cand <= pairs && __ballot(safe < cand) == 0ull) safe_pairs = cand;
+  }
+  const f32x2 dx2 = {dx, dx}, x02 = {x0, x0}, nm12 = {nm1, nm1}, hm2 = {hm, hm};
+  const f32x2 one2 = {1.0f, 1.0f}, two2 = {2.0f, 2.0f};
+  f32x2 j2 = {1.0f, 2.0f};
+  f32x2 acc = {0.0f, 0.0f};
+  int it = 0;
+  for (; it < safe_pairs; it++) {
+    const f32x2 x = __builtin_elementwise_fma(j2, dx2, x02);
+    j2 = j2 + two2;
+    f32x2 lg, P, l1, sr;
     lg.x = lg2(x.x); lg.y = lg2(x.y);
-    const f32x2 nlg = l.n * lg;
-    f32x2 a;
-    a.x = ex2(nlg.x); a.y = ex2(nlg.y);
-    const f32x2 one_a = 1.0f + a;
-    f32x2 l1;
-    l1.x = lg2(one_a.x); l1.y = lg2(one_a.y);
-    const f32x2 e1 = half_m * l1;
-    const f32x2 e2 = l.m * (nlg - l1);
-    f32x2 sq, op;
-    sq.x = ex2(e1.x); sq.y = ex2(e1.y);
-    op.x = ex2(e2.x); op.y = ex2(e2.y);
-    const f32x2 t = 1.0f - op;
-    f32x2 k2 = l.ksat * sq * (t * t);
-    k2.x = (fabsf(h2.x) < 0.1f || h2.x < 0.0f) ? k_sat1 : k2.x;
-    k2.y = (fabsf(h2.y) < 0.1f || h2.y < 0.0f) ? k_sat1 : k2.y;
-    g = g + ((k1 + k2.x) * hdh);
-    g = g + ((k2.x + k2.y) * hdh);
-    k1 = k2.y;
+    const f32x2 e0 = nm12 * lg;
+    P.x = ex2(e0.x); P.y = ex2(e0.y);
+    const f32x2 opa = __builtin_elementwise_fma(x, P, one2);
+    l1.x = lg2(opa.x); l1.y = lg2(opa.y);
+    const f32x2 e1 = hm2 * l1;
+    sr.x = ex2(e1.x); sr.y = ex2(e1.y);
+    const f32x2 t = __builtin_elementwise_fma(-P, sr * sr, one2);
+    acc = acc + sr * (t * t);
   }
-  for (; i < nint; i++) {  // odd nint: last node
-    const float h2 = h_f;
-    const float lg = lg2(l.alpha * h2);
-    const float a = ex2(l.n * lg);
-    const float l1 = lg2(1.0f + a);
-    const float t = 1.0f - ex2(l.m * (l.n * lg - l1));
-    float k2 = l.ksat * ex2(half_m * l1) * (t * t);
-    k2 = (fabsf(h2) < 0.1f || h2 < 0.0f) ? k_sat1 : k2;
-    g = g + ((k1 + k2) * hdh);
-    k1 = k2;
+  for (; it < pairs; it++) {
+    const f32x2 x = __builtin_elementwise_fma(j2, dx2, x02);
+    j2 = j2 + two2;
+    acc.x += node(x.x);
+    acc.y += node(x.y);
   }
-  return fabsf(g / l.ksat);
+  float sum = acc.x + acc.y;
+  if (M & 1) sum += node(__builtin_fmaf(float(M), dx, x0));
+  const float k0 = node(x0), kn = node(l.alpha * h_f);
+  return fabsf((0.5f * dh) * ((k0 + kn) + 2.0f * sum));
 }
 #else
 template <> __device__ __forceinline__ float geff<float>(const LayerK<float> &l, float t1, float t2, int nint) {
@@ -374,6 +401,12 @@ template <typename S, int NL, int FMAX> struct Column {
   __device__ __forceinline__ S cum_at(int k) const { return sel<S, NL>(P.cum, k); }
   // calc_geff (lgar/green_ampt.py:19-99): trapezoid or closed form, per cfg.data.use_closed_form_G
   __device__ __forceinline__ S capillary_drive(const LayerK<S> &lk, S theta1, S theta2) const {
+#ifdef LGAR_DUP_GEFF
+    if constexpr (sizeof(S) == sizeof(R)) {
+      const S extra = geff(lk, opaque(theta1), opaque(theta2), G.nint);
+      if (val(extra) == R(12345.678)) return extra;  // practically never true: keeps the duplicate alive
+    }
+#endif
     return G.closed_form ? geff_closed(lk, theta1, theta2) : geff(lk, theta1, theta2, G.nint);
   }
   __device__ __forceinline__ S cum_prev(int k) const {  // cum[k-1], 0 for k == 0
@@ -698,6 +731,12 @@ template <typename S, int NL, int FMAX> struct Column {
         need_search = true;
       }
       if (need_search) {
+#ifdef LGAR_DUP_SEARCH
+        if constexpr (sizeof(S) == sizeof(R)) {
+          const S extra = theta_mass_balance(k, lk, opaque(t_psi), opaque(t_new), opaque(t_prior), dth, dthick, t_dth_k, t_dthick_k);
+          if (val(extra) == R(-1.0)) status |= LGAR_ST_STRUCT;  // never true
+        }
+#endif
         S theta_new = theta_mass_balance(k, lk, t_psi, t_new, t_prior, dth, dthick, t_dth_k, t_dthick_k);
         F.TH(i) = mn(theta_new, lk.te);
         need_psi = true;
@@ -858,15 +897,23 @@ template <typename S, int NL, int FMAX> struct Column {
   // crashing in the layer-boundary step first; here that case sets LGAR_ST_BOTTOM and the flux is 0.
   __device__ __forceinline__ S move_wetting_front(S infiltration, S &aet, S old_mass, int fdd) {
     move_sweep(infiltration, aet, old_mass, fdd);
+#ifndef LGAR_SKIP_SCANS
     for (int pass = 0; pass < 2; pass++) {
       merge_fronts();
       if (pass == 0) cross_layer_boundary();
     }
+#endif
     S bottom_flux = S(R(0.0));
     if (G.bottom_mode != 0) bottom_flux = cross_domain_boundary();
+#ifndef LGAR_SKIP_SCANS
     S mass_change = fix_dry_over_wet();
     if (ab(val(mass_change)) > R(1e-7)) aet = aet - mass_change;
+#endif
     update_psi();
+#ifdef LGAR_DUP_PSI
+    asm volatile("" ::: "memory");
+    update_psi();
+#endif
     return bottom_flux;
   }
 
@@ -1079,6 +1126,11 @@ template <typename S, int NL, int FMAX> struct Column {
         }
       }
       calc_dzdt(ponded_depth_sub);
+#ifdef LGAR_DUP_MB
+      ending_volume_sub = mass_balance();
+      asm volatile("" ::: "memory");
+      if (val(ending_volume_sub) == R(-1.0)) status |= LGAR_ST_STRUCT;  // never true
+#endif
       ending_volume_sub = mass_balance();
       previous_precip = precip_sub;
       ending_volume = ending_volume_sub;
@@ -1098,9 +1150,11 @@ template <typename S, int NL, int FMAX> struct Column {
         a_giuh = a_giuh + now;
         a_disch = a_disch + now;
       }
+#ifndef LGAR_SKIP_NANSCAN
       bool bad = false;
       for (int i = 0; i < nf; i++) bad = bad || is_nan(val(F.TH(i))) || is_nan(val(F.Z(i))) || is_nan(val(F.PS(i)));
       if (bad) status |= LGAR_ST_NAN;
+#endif
     }
   }
 };

@@ -113,8 +113,14 @@ __device__ __forceinline__ double wave_sum(double v) {
 // Lanes past the last column of a ragged tail wave integrate a copy of the last column (all 64 lanes stay active
 // for the wave reductions) and store nothing.
 // BASIN = false is the lean variant (no epilogue code, tail lanes exit at once); BASIN = true adds the basin epilogue.
+#ifndef LGAR_WAVES_F32
+#define LGAR_WAVES_F32 3
+#endif
+#ifndef LGAR_WAVES_F64
+#define LGAR_WAVES_F64 2
+#endif
 template <typename R, int NL, int FMAX, bool BASIN>
-__global__ __launch_bounds__(WAVE, (sizeof(R) == 4) ? 3 : 2) void lgar_forward_kernel(KArgs<R> a) {
+__global__ __launch_bounds__(WAVE, (sizeof(R) == 4) ? LGAR_WAVES_F32 : LGAR_WAVES_F64) void lgar_forward_kernel(KArgs<R> a) {
   __shared__ WaveLDS<R, FMAX> lds;
   const int lane = threadIdx.x;
   const size_t N = (size_t)a.N;

@@ -9,7 +9,7 @@ import ctypes as C
 import torch
 
 from . import _capi
-from ._capi import ACC_NAMES, FMAX, GMAX, LMAX, LMIN, NACC, NSCAL, LgarError
+from ._capi import ACC_NAMES, GMAX, LMAX, LMIN, NACC, NSCAL, LgarError
 
 
 def _require_gpu(device):
@@ -82,6 +82,7 @@ class LgarEngine:
         d.bottom_mode = int(bottom_mode)
         d.use_closed_form_G = int(bool(use_closed_form_G))
 
+        FMAX = _capi.FMAX
         z = lambda *shape, dt=dtype: torch.zeros(*shape, dtype=dt, device=self.device)
         self.depth, self.theta, self.psi = z(FMAX, N), z(FMAX, N), z(FMAX, N)
         self.k, self.dzdt = z(FMAX, N), z(FMAX, N)

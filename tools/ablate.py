@@ -1,0 +1,83 @@
+"""Cost attribution of the forward kernel (dev tool).
+
+`python tools/ablate.py build` (CPU container: hipcc cross-compiles) builds measurement variants of liblgar_hip.so:
+duplication variants (-DLGAR_DUP_<X>: routine X runs twice, results unchanged => time delta = cost of X), skip variants
+and occupancy variants.  `python tools/ablate.py run [f32|f64] [columns]` (GPU box) times the bench workload's forward
+launch on each variant in a fresh child process and prints one JSON line per variant.
+"""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+VARIANTS = {
+    "base": [],
+    "dup_geff": ["-DLGAR_DUP_GEFF"],
+    "dup_search": ["-DLGAR_DUP_SEARCH"],
+    "dup_psi": ["-DLGAR_DUP_PSI"],
+    "dup_mb": ["-DLGAR_DUP_MB"],
+    "skip_nanscan": ["-DLGAR_SKIP_NANSCAN"],
+    "skip_scans": ["-DLGAR_SKIP_SCANS"],
+    "w2": ["-DLGAR_WAVES_F32=2", "-DLGAR_WAVES_F64=1"],
+    "w4_f8": ["-DLGAR_WAVES_F32=4", "-DLGAR_FMAX=8"],
+    "w3_f8": ["-DLGAR_FMAX=8"],
+    "w2_f8": ["-DLGAR_WAVES_F32=2", "-DLGAR_FMAX=8"],
+}
+
+CHILD = r"""
+import json, os, sys, time
+sys.path.insert(0, %(root)r)
+import numpy as np, torch
+import lgar_py_amd as lg
+from lgar_py_amd import workloads as W
+dtype = torch.float32 if %(dt)r == "f32" else torch.float64
+N = %(n)d
+f = W.synth1_forcing(); T = f.shape[0]
+P = W.perturbed_columns(N, seed=0)
+sc = torch.tensor(W.forcing_scale(N, seed=1000), device="cuda")
+eng = lg.LgarEngine(P["alpha"], P["n"], P["ksat"], P["theta_e"], P["theta_r"], P["thickness"], dt_h=300.0 / 3600.0,
+                    ponded_depth_max=0.0, dtype=dtype)
+pr = (torch.tensor(f[:, 0], device="cuda")[:, None] * sc[None, :]).to(dtype).contiguous()
+pe = torch.zeros_like(pr)
+out = {"runoff": torch.empty(T, N, dtype=dtype, device="cuda"), "percolation": torch.empty(T, N, dtype=dtype, device="cuda")}
+ms = []
+for rep in range(%(reps)d):
+    eng.reset()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    eng.forward(pr, pe, series=("runoff", "percolation"), out=out, check=False)
+    b.record(); torch.cuda.synchronize()
+    ms.append(a.elapsed_time(b))
+ms = sorted(ms[1:])
+print(json.dumps(dict(variant=%(name)r, dtype=%(dt)r, columns=N, ms_median=ms[len(ms) // 2], ms_min=ms[0],
+                      col_steps_per_s=N * T / (ms[len(ms) // 2] * 1e-3), faulted=int((eng.status != 0).sum()),
+                      runoff_sum=float(out["runoff"].double().sum()))))
+"""
+
+
+def main():
+    from lgar_py_amd import build as B
+    what = sys.argv[1] if len(sys.argv) > 1 else "build"
+    names = [v for v in os.environ.get("LGAR_VARIANTS", "").split(",") if v] or list(VARIANTS)
+    if what == "build":
+        for nm in names:
+            print(nm, B.build_variant(nm, VARIANTS[nm]), flush=True)
+        return
+    dt = sys.argv[2] if len(sys.argv) > 2 else "f32"
+    n = int(sys.argv[3]) if len(sys.argv) > 3 else 1 << 20
+    for nm in names:
+        lib = os.path.join(B.CSRC, "variants", "liblgar_hip_%s.so" % nm)
+        if not os.path.exists(lib):
+            print(json.dumps(dict(variant=nm, error="not built")), flush=True)
+            continue
+        env = dict(os.environ, LGAR_LIB=lib)
+        code = CHILD % dict(root=ROOT, dt=dt, n=n, reps=6, name=nm)
+        p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        print(p.stdout.strip() or json.dumps(dict(variant=nm, error=p.stderr[-400:])), flush=True)
+
+
+if __name__ == "__main__":
+    main()
