@@ -186,7 +186,7 @@ def valu_probe_record(dev):
                 b.record()
                 torch.cuda.synchronize(dev)
                 if rc == 0:
-                    best = max(best, nwg * iters * 64 / (a.elapsed_time(b) * 1e-3))
+                    best = max(best, nwg * iters * lib.lgar_valu_probe_insts(op) / (a.elapsed_time(b) * 1e-3))
         rec[nm] = best
     return rec
 
@@ -291,6 +291,7 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    eng.geff_wave_calls()  # reset the measurement counter
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -311,7 +312,7 @@ def main():
     faulted = torch.tensor([int((eng.status != 0).sum().item())], device=dev)
     if world > 1:
         all_reduce(faulted)
-    geff_waves = eng.geff_wave_calls() if hasattr(eng, "geff_wave_calls") else None
+    geff_waves = eng.geff_wave_calls() / max(args.steps, 1)  # per launch
 
     if rank == 0:
         units = N * world * T * args.steps
@@ -350,16 +351,16 @@ def main():
                   "peak_v_exp_f32": probe["v_exp_f32"], "peak_v_log_f32": probe["v_log_f32"],
                   "peak_v_fma_f32": probe["v_fma_f32"], "peak_geff_mix": probe["geff_mix"],
                   "definition": "peaks measured live by lgar_valu_probe (64-instruction unrolled inline-asm loops, best of 2 "
-                                "and 4 waves/SIMD); geff_mix = the packed Geff loop's own mix (per 64: 8 v_log, 12 v_exp, 24 "
-                                "packed, 20 plain)"}
+                                "and 4 waves/SIMD); geff_mix = the lean Geff loop's own instruction stream (per node pair: 4 v_log, "
+                                "4 v_exp, 10 packed)"}
             if geff_waves is not None:
                 nint = 120
-                trans = geff_waves * (nint * 5 + 12)  # wave-instructions: 5 per node + the 4 pows / 2 sqrt-free K of the end points
+                trans = geff_waves * ((nint + 1) * 4 + 9)  # wave-instructions: 4 per node + the two h(Se) pows and K_r(Se=1)
                 vr["geff_wave_calls_per_launch"] = geff_waves
                 vr["achieved_geff_transcendentals"] = trans / (kern_ms * 1e-3)
                 peak_t = 0.5 * (probe["v_exp_f32"] + probe["v_log_f32"])
                 vr["frac_of_transcendental_peak"] = trans / (kern_ms * 1e-3) / peak_t if peak_t else None
-                mix_insts = geff_waves * (nint / 2) * 32  # the loop body: 32 instructions per node pair
+                mix_insts = geff_waves * ((nint - 1) // 2) * 18  # the loop body: 18 instructions per node pair
                 vr["frac_of_geff_mix_peak"] = mix_insts / (kern_ms * 1e-3) / probe["geff_mix"] if probe["geff_mix"] else None
             if pmc:
                 vr["pmc"] = pmc

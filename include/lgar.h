@@ -11,7 +11,7 @@
  *  - Plain pointers + sizes; no torch types.  Every pointer is DEVICE memory owned by the caller
  *    (the library never allocates, frees or copies host<->device), valid on the given stream.
  *  - All arrays are struct-of-arrays, COLUMN-FASTEST: a per-layer quantity is [n_layers][n_columns],
- *    a per-front quantity [LGAR_FMAX][n_columns], a forcing / per-step series [n_steps][n_columns].
+ *    a per-front quantity [front_slots][n_columns], a forcing / per-step series [n_steps][n_columns].
  *  - dtype: LGAR_F32 or LGAR_F64 selects the element type of every `void*` array (float / double).
  *  - Return value: 0 ok; <0 argument / launch error (LGAR_E_*).  Physics faults never abort the
  *    launch: they set bits in status[column] (the reference raises Python exceptions instead:
@@ -28,11 +28,15 @@
 extern "C" {
 #endif
 
-#ifndef LGAR_FMAX
-#define LGAR_FMAX 12  /* front slots per column (reference lists are unbounded, observed <= 8; overflow -> status bit) */
-#endif
+/* Front capacity.  The reference's per-layer front lists are unbounded (layers/Layer.py:1336-1416; observed <= 8 on the
+ * bundled cases).  The kernels keep a wave's front table in LDS and are compiled for three capacities; lgar_forward
+ * starts with the smallest that fits and hands the (rare) columns that outgrow it to the next one in the same call, so a
+ * column can hold up to LGAR_FMAX fronts (LGAR_ST_OVERFLOW beyond) while the common case runs at the occupancy of 8. */
+#define LGAR_CAP_SMALL 8
+#define LGAR_CAP_MID 16
+#define LGAR_FMAX 32
 #define LGAR_LMIN 2   /* the reference itself needs >= 2 layers (Layer.py:204) */
-#define LGAR_LMAX 4   /* soil layers: kernels are compiled for 2, 3 and 4 (BASELINE configs: 3) */
+#define LGAR_LMAX 6   /* soil layers: kernels are compiled for 2 .. 6 (BASELINE configs: 3; the reference builds any number, Layer.py:77-89) */
 #define LGAR_GMAX 8   /* GIUH ordinates */
 #define LGAR_NSCAL (3 + LGAR_GMAX) /* scalars row count: ponded_water, previous_precip, ending_volume, giuh_queue[GMAX] */
 #define LGAR_NACC 10  /* precip, PET, AET, infiltration, runoff, percolation, giuh_runoff, discharge, ponded_water, ending_volume */
@@ -52,6 +56,12 @@ extern "C" {
 #define LGAR_ST_ITERCAP 16
 #define LGAR_ST_BOTTOM 32
 #define LGAR_ST_STRUCT 64
+#define LGAR_ST_FAULT_MASK 0x7f
+/* internal to a lgar_forward call (never set when it returns): the column was handed to the next kernel of the
+ * front-capacity chain at the step index held in bits 8..31 */
+#define LGAR_ST_RESUME 128
+#define LGAR_ST_STEP_SHIFT 8
+#define LGAR_NCOUNTERS 4  /* LgarStepOut.counters: [0] wave-level Geff evaluations of the launch; [1..3] reserved */
 
 /* front flag byte: low 7 bits layer number, bit 7 = to_bottom (layers/WettingFront.py:39,49) */
 #define LGAR_FLAG_BOTTOM 0x80
@@ -71,7 +81,8 @@ typedef struct {
                              (Layer.py:1010-1053) turns the overshoot into percolation.  Parity of mode 1 is unpinned. */
   int32_t use_closed_form_G; /* cfg.data.use_closed_form_G: Brooks-Corey closed-form capillary drive
                                 (lgar/green_ampt.py:85-98) instead of the nint-interval trapezoid (:45-84) */
-  int32_t reserved;
+  int32_t front_slots;       /* rows of the per-front state arrays, 3 .. LGAR_FMAX (0 = LGAR_FMAX): the most fronts a
+                                column can hold in this state buffer */
   double dt_h;               /* cfg.models.subcycle_length_h */
   double initial_psi;        /* cfg.data.initial_psi */
   double ponded_depth_max;   /* cfg.data.ponded_depth_max */
@@ -92,8 +103,9 @@ typedef struct {
  * graph (layers/Layer.py:62-90, layers/WettingFront.py:38-49) and the model attributes
  * ponded_water / previous_precip / ending_volume / giuh_runoff_queue (models/dpLGAR.py:128-147). */
 typedef struct {
-  void *depth, *theta, *psi, *k, *dzdt; /* each [LGAR_FMAX][n_columns], fronts ordered top -> bottom */
-  uint8_t *flags;                        /* [LGAR_FMAX][n_columns] */
+  void *depth, *theta, *psi, *k, *dzdt; /* each [front_slots][n_columns], fronts ordered top -> bottom; rows at and
+                                           beyond n_fronts[column] are not meaningful */
+  uint8_t *flags;                        /* [front_slots][n_columns] */
   int32_t *n_fronts;                     /* [n_columns] */
   void *scalars;                         /* [LGAR_NSCAL][n_columns] */
   void *totals;                          /* [LGAR_NACC][n_columns]: run totals, what MassBalance accumulates
@@ -114,13 +126,19 @@ typedef struct {
  *   (the caller zeroes it; what MassBalance.report_mass / the agent's y_hat aggregate over a basin).  Reduced in the
  *   kernel (wave reduction + one fp64 atomic per wave and step): the [n_steps][n_columns] series need not exist.
  *   Summation order across waves is not fixed, so values can differ in the last bits between runs.
- * weights: [n_columns] (dtype) or NULL = 1: e.g. area fractions. */
+ * weights: [n_columns] (dtype) or NULL = 1: e.g. area fractions.
+ * counters[0] += number of wave-level Geff evaluations (calc_geff, lgar/green_ampt.py:19-99) of the launch: what
+ *   bench.py prices against the chip's measured transcendental issue rate. */
 typedef struct {
   void *series[LGAR_NACC];
   double *basin;
   const void *weights;
   uint32_t basin_mask;
   uint32_t reserved;
+  uint64_t *counters; /* NULL or device uint64[LGAR_NCOUNTERS], accumulated (caller zeroes): measurement only */
+  void *call_sums;    /* NULL or [LGAR_NACC][n_columns] (dtype): rows 0..7 = the accumulators summed over THIS call's
+                         steps (what the model attributes gain over a block of forward() calls, models/dpLGAR.py:271-298),
+                         rows 8, 9 = latest ponded_water / ending_volume */
 } LgarStepOut;
 
 const char *lgar_version(void);
@@ -152,6 +170,7 @@ int32_t lgar_forward_tangent(const LgarDims *dims, const LgarParams *params, con
 /* Leaf kernels (known-answer tests on the GPU), element-wise over n items:
  * op 0 theta_from_h(x), 1 se_from_h(x), 2 k_from_se(x), 3 h_from_se(x)      (physics/utils.py:35-174)
  * op 4 geff(theta1 = x, theta2 = y)                                        (lgar/green_ampt.py:45-84)
+ * op 6 the same trapezoid evaluated operation by operation like the reference (4 pow + sqrt per node, running h)
  * op 5 aet(psi = x, pet = y, dt_h = z)                                      (lgar/aet.py:17-51)
  * alpha, n, ksat, theta_e, theta_r: [n] per-item soil parameters. */
 int32_t lgar_leaf_batch(int32_t op, int32_t n_items, const void *x, const void *y, double z, const void *alpha,
@@ -160,7 +179,7 @@ int32_t lgar_leaf_batch(int32_t op, int32_t n_items, const void *x, const void *
 
 /* Measurement only (no reference counterpart): vector-ALU issue-rate probe, the compute-side roof bench.py prices the
  * path against (the path is VALU-bound: ~10^3 flop per algorithmic byte).  Launches n_workgroups one-wave workgroups,
- * each running `iters` iterations of 64 instructions of kind `op`; lds_bytes_per_workgroup sets the resident waves
+ * each running `iters` iterations of lgar_valu_probe_insts(op) instructions of kind `op`; lds_bytes_per_workgroup sets the resident waves
  * per SIMD (160 KiB / (4 k) => k).  sink: device float[n_workgroups * 64] (never written in practice).  The caller
  * times the launch on `stream`. */
 #define LGAR_PROBE_EXP 0      /* v_exp_f32, 8 independent chains */
@@ -179,7 +198,7 @@ int32_t lgar_leaf_batch(int32_t op, int32_t n_items, const void *x, const void *
 #define LGAR_PROBE_MUL64 13   /* v_mul_f64 */
 #define LGAR_PROBE_ADD64 14   /* v_add_f64 */
 #define LGAR_PROBE_RCP64 15   /* v_rcp_f64 */
-#define LGAR_PROBE_GEFF_MIX 16 /* the instruction mix of the packed fp32 Geff loop: per 64: 8 v_log, 12 v_exp, 24 packed, 20 plain */
+#define LGAR_PROBE_GEFF_MIX 16 /* the instruction stream of the lean fp32 Geff loop: per node pair 4 v_log, 4 v_exp, 10 packed */
 #define LGAR_PROBE_CNDMASK_SGPR 17 /* v_cndmask_b32 with an SGPR-pair mask */
 #define LGAR_PROBE_BFI 18      /* v_bfi_b32 (bitwise select on a vector mask) */
 #define LGAR_PROBE_CMP_CNDMASK 19 /* v_cmp_lt_f32 + v_cndmask_b32 pairs */
@@ -187,7 +206,7 @@ int32_t lgar_leaf_batch(int32_t op, int32_t n_items, const void *x, const void *
 #define LGAR_PROBE_READLANE 21 /* v_readlane_b32 (what an SGPR spill reload costs) */
 #define LGAR_PROBE_DS_READ 22  /* ds_read_b32, lane-contiguous */
 #define LGAR_PROBE_MIN 23      /* v_min_f32 */
-#define LGAR_PROBE_INSTS_PER_ITER 64
+int32_t lgar_valu_probe_insts(int32_t op); /* wave-instructions per probe iteration: 64 (72 for LGAR_PROBE_GEFF_MIX) */
 int32_t lgar_valu_probe(int32_t op, int32_t n_workgroups, int32_t lds_bytes_per_workgroup, int32_t iters, void *sink,
                         void *stream);
 

@@ -8,7 +8,10 @@ import os
 
 from . import build as _build
 
-FMAX, LMIN, LMAX, GMAX = 12, 2, 4, 8
+FMAX, LMIN, LMAX, GMAX = 32, 2, 6, 8
+CAP_SMALL, CAP_MID = 8, 16
+NCOUNTERS = 4
+ST_RESUME, ST_FAULT_MASK = 128, 0x7F
 NSCAL = 3 + GMAX
 NACC = 10
 F32, F64 = 0, 1
@@ -18,13 +21,13 @@ ST_NAN, ST_NEGBASE, ST_THETA_ORDER, ST_OVERFLOW, ST_ITERCAP, ST_BOTTOM, ST_STRUC
 STATUS_NAMES = {1: "NaN", 2: "negative pow base", 4: "theta order", 8: "front overflow", 16: "iteration cap",
                 32: "front reached domain bottom", 64: "structural error"}
 EXPORTS = ["lgar_version", "lgar_fmax", "lgar_lmax", "lgar_state_init", "lgar_forward", "lgar_forward_tangent",
-           "lgar_leaf_batch", "lgar_valu_probe"]
+           "lgar_leaf_batch", "lgar_valu_probe", "lgar_valu_probe_insts"]
 
 
 class LgarDims(C.Structure):
     _fields_ = [("n_columns", C.c_int32), ("n_layers", C.c_int32), ("n_steps", C.c_int32),
                 ("num_subcycles", C.c_int32), ("nint", C.c_int32), ("n_giuh", C.c_int32),
-                ("search_mode", C.c_int32), ("bottom_mode", C.c_int32), ("use_closed_form_G", C.c_int32), ("reserved", C.c_int32),
+                ("search_mode", C.c_int32), ("bottom_mode", C.c_int32), ("use_closed_form_G", C.c_int32), ("front_slots", C.c_int32),
                 ("dt_h", C.c_double), ("initial_psi", C.c_double), ("ponded_depth_max", C.c_double),
                 ("wilting_point_psi", C.c_double), ("frozen_factor", C.c_double), ("giuh", C.c_double * GMAX),
                 ("iter_cap", C.c_int64)]
@@ -44,7 +47,7 @@ class LgarForcing(C.Structure):
 
 
 class LgarStepOut(C.Structure):
-    _fields_ = [("series", C.c_void_p * NACC), ("basin", C.c_void_p), ("weights", C.c_void_p), ("basin_mask", C.c_uint32), ("reserved", C.c_uint32)]
+    _fields_ = [("series", C.c_void_p * NACC), ("basin", C.c_void_p), ("weights", C.c_void_p), ("basin_mask", C.c_uint32), ("reserved", C.c_uint32), ("counters", C.c_void_p), ("call_sums", C.c_void_p)]
 
 
 class LgarError(RuntimeError):
@@ -59,16 +62,17 @@ def lib_path():
 
 
 def load():
-    """Load liblgar_hip.so (building it if the sources are newer); raise loudly if that is impossible."""
+    """Load liblgar_hip.so, (re)building it first when it is missing or was built from other sources (content
+    fingerprint, build.py); raise loudly if that is impossible."""
     global _lib
     if _lib is not None:
         return _lib
     path = _build.LIB
-    if not os.path.exists(path):
+    if not os.environ.get("LGAR_LIB"):  # an explicitly selected library (measurement variants) is taken as it is
         try:
             _build.build()
         except Exception as e:  # noqa: BLE001
-            raise LgarError("liblgar_hip.so is missing and could not be built (%s); there is no CPU fallback" % e)
+            raise LgarError("liblgar_hip.so is missing or stale and could not be built (%s); there is no CPU fallback" % e)
     try:
         lib = C.CDLL(path)
     except OSError as e:
@@ -88,11 +92,10 @@ def load():
                                              i32, vp]
     lib.lgar_leaf_batch.restype = i32
     lib.lgar_leaf_batch.argtypes = [i32, i32, vp, vp, dbl, vp, vp, vp, vp, vp, i32, dbl, vp, i32, vp]
+    lib.lgar_valu_probe_insts.restype = i32
+    lib.lgar_valu_probe_insts.argtypes = [i32]
     lib.lgar_valu_probe.restype = i32
     lib.lgar_valu_probe.argtypes = [i32, i32, i32, i32, vp, vp]
-    global FMAX
-    if os.environ.get("LGAR_LIB"):
-        FMAX = lib.lgar_fmax()  # measurement variants (tools/ablate.py) may be built with another front capacity
     if lib.lgar_fmax() != FMAX or lib.lgar_lmax() != LMAX:
         raise LgarError("liblgar_hip.so was built with different LGAR_FMAX/LGAR_LMAX than the Python binding")
     _lib = lib

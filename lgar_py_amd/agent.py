@@ -26,8 +26,9 @@ class RangeBoundLoss(nn.Module):
     def forward(self, params):
         loss = torch.tensor(0.0, dtype=torch.float64)
         for i in range(len(params) - 1):
-            t = torch.stack([p.reshape(-1).mean() if p.dim() else p for p in params[i]]).cpu()
-            loss = loss + torch.sum(self.factor * torch.relu(t - self.ub[i])) + torch.mean(self.factor * torch.relu(self.lb[i] - t))
+            # every element is bounded (per-column ensembles: [N] per layer), as the reference bounds each of its scalars
+            t = torch.stack([p.reshape(-1) for p in params[i]]).cpu()  # [L, N] (N = 1 for the single column)
+            loss = loss + torch.sum(self.factor * torch.relu(t - self.ub[i]).mean(1)) + torch.mean(self.factor * torch.relu(self.lb[i] - t))
         t = params[-1].cpu()
         return loss + self.factor * torch.relu(t - self.ub[-1]) + self.factor * torch.relu(self.lb[-1] - t)
 

@@ -2,14 +2,20 @@
 
 The reference differentiates forward() by recording every scalar torch op
 (/root/reference/dpLGAR/agents/DifferentiableLGAR.py:119,163).  Here the vector-Jacobian product is assembled from
-forward-mode tangents computed on the GPU (csrc/lgar_tangent.hip): columns are independent, so one tangent launch
+forward-mode tangents computed on the GPU (csrc/lgar_tangent_nl.hip): columns are independent, so one tangent launch
 with a one-hot direction over (alpha | n | Ksat, layer) yields d runoff_t / d p for every column's own parameter,
 contracted on the fly with the incoming gradient.  3 x L launches per backward, nothing stored per step.
 Line-search offsets are constants w.r.t. the parameters, exactly as in the reference (Layer.py:277-288, 683-696).
+
+Both entry points are ordinary torch.autograd.Function nodes whose inputs are the parameters, so the outputs carry a
+grad_fn that reaches them (models/dpLGAR.py:299) and torch.autograd.grad / loss.backward() both work.
 """
+import weakref
+
 import torch
 
-from .engine import LgarEngine
+from ._capi import ST_FAULT_MASK
+from .engine import LgarEngine, LgarError, LgarStatusError
 
 KINDS = ("alpha", "n", "ksat")
 # below this many (column, direction) pairs all directions of a backward pass ride as extra columns of ONE tangent
@@ -17,14 +23,18 @@ KINDS = ("alpha", "n", "ksat")
 BATCH_DIRECTIONS_MAX_COLUMNS = 1 << 16
 
 
-def parameter_vjp(eng, precip, pet, w_runoff, w_perc, wanted):
+def parameter_vjp(eng, precip, pet, w_runoff, w_perc, wanted, check=True):
     """Vector-Jacobian product for every (kind, layer) in `wanted` (list of (kind, l)).
-    Returns {(kind, l): grad[N]}.  Columns are independent, so for small jobs the directions are laid side by side as
-    len(wanted) * N columns of a single launch; large jobs loop over directions (same total work, N-column memory)."""
+    Returns ({(kind, l): grad[N]}, tangent_status[N]).  Columns are independent, so for small jobs the directions are laid
+    side by side as len(wanted) * N columns of a single launch; large jobs loop over directions (same total work,
+    N-column memory).  A column whose tangent integration faults (status != 0: NaN, iteration cap, front overflow ...)
+    has no valid gradient: with check=True that raises LgarStatusError (a ValueError, like the reference's physics
+    faults), with check=False its gradient entries are zeroed and the status tensor says which columns those are."""
     L, N, D = eng.L, eng.N, len(wanted)
     out = {}
+    status = torch.zeros(N, dtype=torch.int32, device=eng.device)
     if D == 0:
-        return out
+        return out, status
     if D * N <= BATCH_DIRECTIONS_MAX_COLUMNS and D > 1:
         rep = lambda t: t.repeat(1, D)
         d = eng.dims
@@ -33,20 +43,31 @@ def parameter_vjp(eng, precip, pet, w_runoff, w_perc, wanted):
                          ponded_depth_max=d.ponded_depth_max, wilting_point_psi=d.wilting_point_psi,
                          frozen_factor=d.frozen_factor, nint=d.nint, giuh_ordinates=tuple(d.giuh[i] for i in range(d.n_giuh)),
                          dtype=eng.dtype, device=eng.device, iter_cap=d.iter_cap, search_mode=d.search_mode,
-                         bottom_mode=d.bottom_mode, use_closed_form_G=bool(d.use_closed_form_G))
+                         bottom_mode=d.bottom_mode, use_closed_form_G=bool(d.use_closed_form_G), front_slots=eng.front_slots)
         dirs = {k: torch.zeros(L, D * N, dtype=eng.dtype, device=eng.device) for k in KINDS}
         for b, (kind, l) in enumerate(wanted):
             dirs[kind][l, b * N:(b + 1) * N] = 1.0
         tile = lambda t: None if t is None else t.repeat(1, D)
-        g, _, _ = big.tangent(dirs, tile(precip), tile(pet), w_runoff=tile(w_runoff), w_perc=tile(w_perc))
+        g, _, st = big.tangent(dirs, tile(precip), tile(pet), w_runoff=tile(w_runoff), w_perc=tile(w_perc))
         for b, key in enumerate(wanted):
             out[key] = g[b * N:(b + 1) * N]
-        return out
-    for kind, l in wanted:
-        dmat = torch.zeros(L, N, dtype=eng.dtype, device=eng.device)
-        dmat[l] = 1.0
-        out[(kind, l)], _, _ = eng.tangent({kind: dmat}, precip, pet, w_runoff=w_runoff, w_perc=w_perc)
-    return out
+            status |= st[b * N:(b + 1) * N]
+    else:
+        for kind, l in wanted:
+            dmat = torch.zeros(L, N, dtype=eng.dtype, device=eng.device)
+            dmat[l] = 1.0
+            out[(kind, l)], _, st = eng.tangent({kind: dmat}, precip, pet, w_runoff=w_runoff, w_perc=w_perc)
+            status |= st
+    status &= ST_FAULT_MASK
+    bad = status != 0
+    if bool(bad.any()):
+        if check:
+            first = int(torch.nonzero(bad)[0].item())
+            raise LgarStatusError("%d of %d columns faulted in the tangent (gradient) integration; first column %d, status %d"
+                                  % (int(bad.sum().item()), N, first, int(status[first].item())))
+        for key in out:
+            out[key] = torch.where(bad, torch.zeros_like(out[key]), out[key])
+    return out, status
 
 
 class LgarSeriesFunction(torch.autograd.Function):
@@ -64,6 +85,8 @@ class LgarSeriesFunction(torch.autograd.Function):
         ctx.engine = eng
         ctx.forcing = (precip, pet)
         ctx.in_dtypes = (alpha.dtype, n.dtype, ksat.dtype)
+        ctx.check = check
+        ctx.status_out = status_out
         return out["runoff"], out["percolation"]
 
     @staticmethod
@@ -71,64 +94,108 @@ class LgarSeriesFunction(torch.autograd.Function):
         eng = ctx.engine
         precip, pet = ctx.forcing
         wanted = [(kind, l) for ki, kind in enumerate(KINDS) if ctx.needs_input_grad[ki] for l in range(eng.L)]
-        vj = parameter_vjp(eng, precip, pet, g_runoff, g_perc, wanted)
+        # columns that already faulted in the forward run are the caller's to mask (status_out); they carry no gradient
+        fwd_bad = (eng.status & ST_FAULT_MASK) != 0
+        keep = (~fwd_bad).to(g_runoff.dtype)[None, :] if g_runoff is not None else None
+        gr = None if g_runoff is None else g_runoff * keep
+        gp = None if g_perc is None else g_perc * ((~fwd_bad).to(g_perc.dtype)[None, :])
+        vj, st = parameter_vjp(eng, precip, pet, gr, gp, wanted, check=False)
+        st = torch.where(fwd_bad, torch.zeros_like(st), st)
+        if ctx.status_out is not None:
+            ctx.status_out.append(st)  # [forward status, tangent status]
+        if ctx.check and bool((st != 0).any()):
+            raise LgarStatusError("%d columns faulted in the tangent (gradient) integration" % int((st != 0).sum().item()))
         grads = []
         for ki, kind in enumerate(KINDS):
             if not ctx.needs_input_grad[ki]:
                 grads.append(None)
                 continue
-            grads.append(torch.stack([vj[(kind, l)] for l in range(eng.L)]).to(ctx.in_dtypes[ki]))
+            g = torch.stack([vj[(kind, l)] for l in range(eng.L)])
+            g = torch.where(fwd_bad[None, :], torch.zeros_like(g), g)
+            grads.append(g.to(ctx.in_dtypes[ki]))
         return (*grads, None, None, None, None, None, None)
 
 
 def lgar_series(alpha, n, ksat, theta_e, theta_r, thickness, precip, pet, **engine_kw):
     """Differentiable run: parameters [L, N] (torch tensors, may require grad), forcing [T, N] -> runoff, percolation [T, N].
-    engine_kw: LgarEngine keywords, plus check=False to keep going when columns fault (mask them with the status
-    tensor appended to the list passed as status_out)."""
+    engine_kw: LgarEngine keywords, plus check=False to keep going when columns fault: pass status_out=[] to receive the
+    forward status tensor (appended by the forward pass) and the tangent status tensor (appended by the backward pass);
+    faulted columns get zero gradient."""
     return LgarSeriesFunction.apply(alpha, n, ksat, theta_e, theta_r, thickness, precip, pet, engine_kw)
+
+
+class _ChunkFunction(torch.autograd.Function):
+    """One model.forward() call's (runoff, percolation) block as an autograd node with the parameters as inputs.
+    `token` chains the nodes of an epoch in call order, so autograd necessarily reaches chunk 0 last: there the weights
+    recorded by all chunks are turned into parameter gradients by ONE batch of tangent launches over the whole series."""
+
+    @staticmethod
+    def forward(ctx, tape, ci, token, runoff, perc, *params):
+        ctx.tape_ref, ctx.ci, ctx.n_params = weakref.ref(tape), ci, len(params)  # the model owns the tape; the graph does not
+        ctx.set_materialize_grads(False)
+        return runoff.clone(), perc.clone(), token.new_zeros(())
+
+    @staticmethod
+    def backward(ctx, g_runoff, g_perc, g_token):
+        tape = ctx.tape_ref()
+        if tape is None:
+            raise LgarError("backward through a model that no longer exists")
+        tape.add_weights(ctx.ci, g_runoff, g_perc)
+        if ctx.ci == 0:
+            return (None, None, None, None, None, *tape.finalize())
+        # a defined (zero) gradient for the token keeps the chain down to chunk 0 alive
+        return (None, None, torch.zeros((), dtype=torch.float64), None, None, *((None,) * ctx.n_params))
 
 
 class StepTape:
     """Autograd for the reference's calling convention (`model(x[i])` once per forcing row -- or a whole [T, N, 2] block --
-    with the loss taken at the end of the epoch).  Every returned runoff/percolation block is a leaf that records the
-    gradient it receives; when the backward pass finishes, ONE batch of tangent launches over the recorded forcing
-    series turns the recorded weights into parameter gradients (accumulated into .grad like autograd would) --
-    O(T) work per epoch, nothing stored per step but the forcing rows."""
+    with the loss taken at the end of the epoch).  Every returned runoff/percolation block is the output of an autograd
+    node whose inputs are the model's parameters; the backward pass records the gradient each block receives and, at the
+    node of the epoch's first block, ONE batch of tangent launches over the recorded forcing series turns the recorded
+    weights into parameter gradients -- O(T) work per epoch, nothing stored per step but the forcing rows."""
 
     def __init__(self, model):
-        self.model = model
+        self._model = weakref.ref(model)  # the model owns the tape, not the other way round
         self.reset()
 
     def reset(self):
-        for h in getattr(self, "handles", []):
-            h.remove()
-        self.handles = []    # hook handles of the leaves handed out
         self.x = []          # forcing chunks [Tc, N, 2] since the last set_internal_states()
         self.w = {}          # (chunk, 0|1) -> gradient received, [Tc, N]
-        self.queued = False
+        self.token = None
+        self.versions = None
+
+    def _param_lists(self):
+        m = self._model()
+        if m is None:
+            raise LgarError("the model this tape belongs to is gone")
+        return m, (("alpha", m.alpha), ("n", m.n), ("ksat", m.ksat))
 
     def record(self, x_chunk, runoff_chunk, perc_chunk):
-        """x_chunk [Tc, N, 2]; runoff/perc [Tc, N].  Returns leaf tensors standing for this chunk's per-step values."""
+        """x_chunk [Tc, N, 2]; runoff/perc [Tc, N] (engine outputs).  Returns the graph-connected blocks."""
+        m, plists = self._param_lists()
+        params = [p for _, pl in plists for p in pl]
+        versions = tuple(p._version for p in params)
+        if self.versions is None:
+            self.versions = versions
+        elif versions != self.versions:
+            raise LgarError("parameters changed in the middle of a recorded series (update_soil_parameters / optimizer step "
+                            "before backward): call set_internal_states() first, the gradient would belong to another run")
         ci = len(self.x)
         self.x.append(x_chunk.detach())
-        outs = []
-        for which, v in enumerate((runoff_chunk, perc_chunk)):
-            leaf = v.detach().clone().requires_grad_(True)
-            self.handles.append(leaf.register_hook(lambda g, ci=ci, which=which: self._on_grad(ci, which, g)))
-            outs.append(leaf)
-        return outs
+        token = self.token if self.token is not None else torch.zeros((), dtype=torch.float64)
+        r, p, self.token = _ChunkFunction.apply(self, ci, token, runoff_chunk, perc_chunk, *params)
+        return r, p
 
-    def _on_grad(self, ci, which, g):
-        key = (ci, which)
-        self.w[key] = self.w[key] + g.detach() if key in self.w else g.detach().clone()
-        if not self.queued:
-            self.queued = True
-            torch.autograd.Variable._execution_engine.queue_callback(self._finalize)
-        return None
+    def add_weights(self, ci, g_runoff, g_perc):
+        for which, g in enumerate((g_runoff, g_perc)):
+            if g is None:
+                continue
+            key = (ci, which)
+            self.w[key] = self.w[key] + g.detach() if key in self.w else g.detach().clone()
 
-    def _finalize(self):
-        self.queued = False
-        m = self.model
+    def finalize(self):
+        """Parameter gradients (in parameter order) from the weights recorded so far; called by chunk 0's backward."""
+        m, plists = self._param_lists()
         eng = m.engine
         X = torch.cat(self.x).to(eng.device, eng.dtype)  # [T, N, 2]
         T = X.shape[0]
@@ -143,21 +210,18 @@ class StepTape:
         self.w = {}
         precip, pet = X[:, :, 0].contiguous(), X[:, :, 1].contiguous()
         ff = float(m.cfg.constants.frozen_factor)
-        plists = (("alpha", m.alpha), ("n", m.n), ("ksat", m.ksat))
         wanted = [(kind, l) for kind, plist in plists for l, p in enumerate(plist) if p.requires_grad]
-        vj = parameter_vjp(eng, precip, pet, W[0], W[1], wanted)
+        vj, _ = parameter_vjp(eng, precip, pet, W[0], W[1], wanted, check=True)
+        grads = []
         for kind, plist in plists:
             for l, p in enumerate(plist):
                 if not p.requires_grad:
+                    grads.append(None)
                     continue
                 g = vj[(kind, l)]
                 if kind == "ksat":
                     g = g / ff  # the Parameter already carries frozen_factor (models/dpLGAR.py:57)
                 g = g.to(torch.float64).to(p.device)
                 g = g.sum() if p.dim() == 0 else g
-                p.grad = g.to(p.dtype) if p.grad is None else p.grad + g.to(p.dtype)
-        # the recorded series is consumed: drop the hooks (they hold this tape, the tape holds the model) so nothing
-        # autograd-related is left for interpreter shutdown to untangle
-        for h in self.handles:
-            h.remove()
-        self.handles = []
+                grads.append(g.to(p.dtype))
+        return tuple(grads)

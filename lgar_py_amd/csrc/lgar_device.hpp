@@ -11,7 +11,9 @@
 // linked list of Layer objects each owning a Python list of WettingFront objects, here a column is
 // ONE flat top->bottom front array tagged with layer numbers.
 #pragma once
+#ifndef LGAR_DEVSIM
 #include <hip/hip_runtime.h>
+#endif
 #include <stdint.h>
 
 #include "../../include/lgar.h"
@@ -35,10 +37,24 @@ __device__ __forceinline__ double pw(double x, double y) { return pow(x, y); }  
 __device__ __forceinline__ double pw(double x, double y) { return fast_pow(x, y); }  // lgar_math.hpp, ~1e-14 relative
 #endif
 // fp32: v_log_f32 / v_exp_f32 (quarter-rate transcendentals), ~2-3 ulp for the exponents used here
-__device__ __forceinline__ float pw(float x, float y) { return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)); }
 // log2 / exp2 (fused Geff node, dual-number pow)
+#ifndef LGAR_DEVSIM
 __device__ __forceinline__ float lg2(float x) { return __builtin_amdgcn_logf(x); }
 __device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float sq(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ unsigned long long any_lane(bool p) { return __ballot(p); }
+__device__ __forceinline__ bool first_active_lane() {
+  const unsigned long long m = __ballot(1);
+  return (int)(threadIdx.x & 63u) == __ffsll((long long)m) - 1;
+}
+#else  // tests/devsim: the same device code compiled for the host, one lane at a time (test infrastructure only)
+__device__ __forceinline__ float lg2(float x) { return log2f(x); }
+__device__ __forceinline__ float ex2(float x) { return exp2f(x); }
+__device__ __forceinline__ float sq(float x) { return sqrtf(x); }
+__device__ __forceinline__ unsigned long long any_lane(bool p) { return p ? 1ull : 0ull; }
+__device__ __forceinline__ bool first_active_lane() { return true; }
+#endif
+__device__ __forceinline__ float pw(float x, float y) { return ex2(y * lg2(x)); }
 #ifdef LGAR_F64_LIBM
 __device__ __forceinline__ double lg2(double x) { return log2(x); }
 __device__ __forceinline__ double ex2(double x) { return exp2(x); }
@@ -47,7 +63,6 @@ __device__ __forceinline__ double lg2(double x) { return fast_log2(x); }
 __device__ __forceinline__ double ex2(double x) { return fast_exp2(x); }
 #endif
 __device__ __forceinline__ double sq(double x) { return sqrt(x); }
-__device__ __forceinline__ float sq(float x) { return __builtin_amdgcn_sqrtf(x); }
 __device__ __forceinline__ double ab(double x) { return fabs(x); }
 __device__ __forceinline__ float ab(float x) { return fabsf(x); }
 __device__ __forceinline__ double mn(double a, double b) { return fmin(a, b); }
@@ -58,8 +73,10 @@ __device__ __forceinline__ bool is_nan(float x) { return x != x; }
 // Cost attribution by duplication (tools/ablate.py builds variants with -DLGAR_DUP_<X>): the named routine runs twice
 // on opaque copies of its inputs, results unchanged, so the time difference to the plain build is that routine's cost
 // with the column dynamics (and therefore all other work) untouched.
+#ifndef LGAR_DEVSIM
 __device__ __forceinline__ float opaque(float x) { asm volatile("" : "+v"(x)); return x; }
 __device__ __forceinline__ double opaque(double x) { asm volatile("" : "+v"(x)); return x; }
+#endif
 
 // tolerances: the reference's absolute 1e-12 (layers/Layer.py:60) is unreachable in fp32
 template <typename R> struct Tol;
@@ -156,7 +173,7 @@ template <typename S> __device__ __forceinline__ S h_from_se(const LayerK<S> &l,
 }
 // calc_geff, models/physics/lgar/green_ampt.py:45-84: nint-interval trapezoid of K(h) dh / Ksat.
 // The discretisation error is part of the answer: same nodes (h accumulated by repeated += dh).
-template <typename S> __device__ __forceinline__ S geff(const LayerK<S> &l, S theta1, S theta2, int nint) {
+template <typename S> __device__ __forceinline__ S geff_literal(const LayerK<S> &l, S theta1, S theta2, int nint) {
   using R = real_t<S>;
   S se_i = se_from_theta(l, theta1);
   S se_f = se_from_theta(l, theta2);
@@ -177,6 +194,10 @@ template <typename S> __device__ __forceinline__ S geff(const LayerK<S> &l, S th
     h2 = h2 + dh;
   }
   return ab(g / l.ksat);
+}
+// the trapezoid the kernels use by default: specialised below for float / double (and the dual numbers, lgar_dual.hpp)
+template <typename S> __device__ __forceinline__ S geff(const LayerK<S> &l, S theta1, S theta2, int nint) {
+  return geff_literal<S>(l, theta1, theta2, nint);
 }
 
 // fp32 Geff: the same 121 nodes with Se(h) -> K(Se) fused per node.  With a = (alpha h)^n:
@@ -267,7 +288,7 @@ template <> __device__ __forceinline__ float geff<float>(const LayerK<float> &l,
   int safe_pairs = 0;  // wave-uniform minimum by bisection on ballots (plain compares + scalar ops)
   for (int bit = 64; bit; bit >>= 1) {
     const int cand = safe_pairs + bit;
-    if (cand <= pairs && __ballot(safe < cand) == 0ull) safe_pairs = cand;
+    if (cand <= pairs && any_lane(safe < cand) == 0ull) safe_pairs = cand;
   }
   const f32x2 dx2 = {dx, dx}, x02 = {x0, x0}, nm12 = {nm1, nm1}, hm2 = {hm, hm};
   const f32x2 one2 = {1.0f, 1.0f}, two2 = {2.0f, 2.0f};
@@ -352,7 +373,7 @@ template <typename S> __device__ __forceinline__ S aet_fn(const LayerK<S> &l, S 
 template <typename R> struct Glob {
   R dt_h, initial_psi, pdm, wp_psi, frozen;
   R giuh[LGAR_GMAX];
-  int nint, nsub, ng, search_mode, bottom_mode, closed_form;
+  int nint, nsub, ng, bottom_mode, closed_form;
   long long iter_cap;
 };
 
@@ -378,7 +399,10 @@ template <typename S> struct FrontsView {
 // ---------------------------------------------------------------------------------------------
 // one soil column
 // ---------------------------------------------------------------------------------------------
-template <typename S, int NL, int FMAX> struct Column {
+// MODE 0: the reference's literal line searches, its update_psi pass and per-sub-step NaN scan.
+// MODE 1 (default of the engine, what bench.py measures): the same roots by bracketed Newton / closed-form jumps; the
+// passes that are provably no-ops between events are skipped (see forward()).
+template <typename S, int NL, int FMAX, int MODE> struct Column {
   using R = real_t<S>;
   const ColParams<S, NL> &P;
   const Glob<R> &G;
@@ -393,6 +417,8 @@ template <typename S, int NL, int FMAX> struct Column {
   // new_front_frozen marks a front created in the current sub-step, whose K carries frozen_factor (Layer.py:1410-1412).
   S k_deepest;
   bool new_front_frozen;
+  unsigned *wave_geff_calls = nullptr;  // wave-level LDS word: Geff evaluations (measurement), may be null
+  int cap = FMAX;                       // fronts this column may hold: min(kernel capacity, rows of the state arrays)
   // accumulators drained every forcing step (physics/MassBalance.py:45-53)
   S a_precip, a_pet, a_aet, a_infil, a_runoff, a_perc, a_giuh, a_disch;
 
@@ -401,12 +427,17 @@ template <typename S, int NL, int FMAX> struct Column {
   __device__ __forceinline__ S cum_at(int k) const { return sel<S, NL>(P.cum, k); }
   // calc_geff (lgar/green_ampt.py:19-99): trapezoid or closed form, per cfg.data.use_closed_form_G
   __device__ __forceinline__ S capillary_drive(const LayerK<S> &lk, S theta1, S theta2) const {
+    if (wave_geff_calls != nullptr && first_active_lane()) *wave_geff_calls += 1u;
 #ifdef LGAR_DUP_GEFF
     if constexpr (sizeof(S) == sizeof(R)) {
       const S extra = geff(lk, opaque(theta1), opaque(theta2), G.nint);
       if (val(extra) == R(12345.678)) return extra;  // practically never true: keeps the duplicate alive
     }
 #endif
+    if constexpr (MODE == 0 && sizeof(R) == 8) {
+      // verification mode: the reference's trapezoid operation by operation (4 pow + sqrt per node, running h)
+      return G.closed_form ? geff_closed(lk, theta1, theta2) : geff_literal(lk, theta1, theta2, G.nint);
+    }
     return G.closed_form ? geff_closed(lk, theta1, theta2) : geff(lk, theta1, theta2, G.nint);
   }
   __device__ __forceinline__ S cum_prev(int k) const {  // cum[k-1], 0 for k == 0
@@ -550,7 +581,7 @@ template <typename S, int NL, int FMAX> struct Column {
     R delta_mass_prev = delta_mass;
     int count_no_change = 0;
     if (delta_mass <= Tol<R>::mass) return theta_from_h(lk, psi);
-    if (G.search_mode != 0) return theta_mass_balance_newton(k, lk, psi, new_mass, prior_mass, dth, dthick, dth_k, dthick_k);
+    if constexpr (MODE != 0) return theta_mass_balance_newton(k, lk, psi, new_mass, prior_mass, dth, dthick, dth_k, dthick_k);
     long long it = 0;
     while (delta_mass > Tol<R>::mass) {
       if (++it > G.iter_cap) { status |= LGAR_ST_ITERCAP; break; }
@@ -598,7 +629,7 @@ template <typename S, int NL, int FMAX> struct Column {
       const bool nxt_same = (fdd + 1 < nf) && (F.layer(fdd + 1) == F.layer(fdd));
       const S slope_s = nxt_same ? F.TH(fdd) - F.TH(fdd + 1) : F.TH(fdd);
       const R slope = val(slope_s);
-      const bool jump = (G.search_mode != 0) && (slope > R(0.0));
+      const bool jump = (MODE != 0) && (slope > R(0.0));
       bool model = jump;
       const S m0 = current_mass, d0 = depth_new;
       long long it = 0;
@@ -616,7 +647,7 @@ template <typename S, int NL, int FMAX> struct Column {
         if (val(current_mass) < val(mass_timestep)) {
           if (jump) {
             R nsteps = (val(mass_timestep) - R(2.0) * Tol<R>::mass - val(current_mass)) / (slope * R(0.01) * factor);
-            if (nsteps > R(3.0)) depth_new = depth_new + (floor(nsteps) - R(2.0)) * (R(0.01) * factor);
+            if (nsteps > R(3.0)) depth_new = depth_new + (R(floor(nsteps)) - R(2.0)) * (R(0.01) * factor);
           }
           depth_new = depth_new + R(0.01) * factor;
           switched = false;
@@ -624,7 +655,7 @@ template <typename S, int NL, int FMAX> struct Column {
           if (!switched) { switched = true; factor = factor * R(0.001); }
           if (jump) {
             R nsteps = (val(current_mass) - val(mass_timestep) - R(2.0) * Tol<R>::mass) / (slope * R(0.01) * factor);
-            if (nsteps > R(3.0)) depth_new = depth_new - (floor(nsteps) - R(2.0)) * (R(0.01) * factor);
+            if (nsteps > R(3.0)) depth_new = depth_new - (R(floor(nsteps)) - R(2.0)) * (R(0.01) * factor);
           }
           depth_new = depth_new - (R(0.01) * factor);
         }
@@ -892,24 +923,49 @@ template <typename S, int NL, int FMAX> struct Column {
     return k;
   }
 
+  // Does any of the post-sweep passes have work to do?  merge (Layer.py:826-892), layer-boundary crossing (:894-1008),
+  // domain-boundary crossing (:1010-1053) and dry-over-wet (:1055-1143) each act only when their trigger holds for some
+  // adjacent pair, and a pass that finds no trigger changes nothing; so when no lane of the wave has a trigger the four
+  // passes are skipped as a block (one cheap scan instead of five).
+  __device__ __forceinline__ bool front_event_pending() const {
+    bool ev = false;
+    S z1 = F.Z(0), t1 = F.TH(0);
+    int f1 = F.fl[0];
+    for (int i = 0; i + 1 < nf; i++) {
+      const S z2 = F.Z(i + 1), t2 = F.TH(i + 1);
+      const int f2 = F.fl[(i + 1) * WAVE];
+      const bool same = ((f1 ^ f2) & 0x7f) == 0;
+      ev = ev || (same && !(f2 & LGAR_FLAG_BOTTOM) && val(z1) > val(z2));   // passing
+      ev = ev || (same && val(t1) <= val(t2));                                // dry over wet
+      ev = ev || (val(z1) > val(cum_at(f1 & 0x7f)));                         // past its layer (or the domain) bottom
+      z1 = z2; t1 = t2; f1 = f2;
+    }
+    return ev;
+  }
+
   // dpLGAR.move_wetting_front, models/dpLGAR.py:340-367.  Returns the bottom-boundary flux.
   // wetting_front_cross_domain_boundary (Layer.py:1010-1053) cannot be reached in the reference without
   // crashing in the layer-boundary step first; here that case sets LGAR_ST_BOTTOM and the flux is 0.
   __device__ __forceinline__ S move_wetting_front(S infiltration, S &aet, S old_mass, int fdd) {
     move_sweep(infiltration, aet, old_mass, fdd);
-#ifndef LGAR_SKIP_SCANS
-    for (int pass = 0; pass < 2; pass++) {
-      merge_fronts();
-      if (pass == 0) cross_layer_boundary();
-    }
-#endif
     S bottom_flux = S(R(0.0));
-    if (G.bottom_mode != 0) bottom_flux = cross_domain_boundary();
-#ifndef LGAR_SKIP_SCANS
-    S mass_change = fix_dry_over_wet();
-    if (ab(val(mass_change)) > R(1e-7)) aet = aet - mass_change;
-#endif
-    update_psi();
+    if (any_lane(front_event_pending()) != 0ull) {
+      for (int pass = 0; pass < 2; pass++) {
+        merge_fronts();
+        if (pass == 0) cross_layer_boundary();
+      }
+      if (G.bottom_mode != 0) bottom_flux = cross_domain_boundary();
+      S mass_change = fix_dry_over_wet();
+      if (ab(val(mass_change)) > R(1e-7)) aet = aet - mass_change;
+      // the passes can leave psi inconsistent with theta (dry-over-wet in a deeper layer writes the psi of ANOTHER
+      // layer's theta into the fronts above it, Layer.py:1117-1143): the reference's update_psi repairs that
+      if constexpr (MODE != 0) update_psi();
+    }
+    // update_psi (Layer.py:1157-1174) re-derives psi from theta for every front but the deepest.  After the sweep alone
+    // every front already carries psi = h(Se(theta)) (in-layer and base-case fronts) or the psi its theta was computed
+    // from (a layer's deepest front), so the pass only adds a theta -> psi -> theta round trip: MODE 0 keeps it, MODE 1
+    // runs it only after an event.
+    if constexpr (MODE == 0) update_psi();
 #ifdef LGAR_DUP_PSI
     asm volatile("" ::: "memory");
     update_psi();
@@ -964,7 +1020,7 @@ template <typename S, int NL, int FMAX> struct Column {
 
   // Layer.create_surficial_front, Layer.py:1336-1416
   __device__ __forceinline__ void create_surficial_front(S dry_depth, S &ponded, S &infiltration) {
-    if (nf >= FMAX) { status |= LGAR_ST_OVERFLOW; return; }
+    if (nf >= cap) { status |= LGAR_ST_OVERFLOW; return; }
     const LayerK<S> l0 = pick_static(P, 0);
     S cur_theta = F.TH(0);
     S delta_theta = l0.te - cur_theta;
@@ -1150,11 +1206,15 @@ template <typename S, int NL, int FMAX> struct Column {
         a_giuh = a_giuh + now;
         a_disch = a_disch + now;
       }
-#ifndef LGAR_SKIP_NANSCAN
-      bool bad = false;
-      for (int i = 0; i < nf; i++) bad = bad || is_nan(val(F.TH(i))) || is_nan(val(F.Z(i))) || is_nan(val(F.PS(i)));
-      if (bad) status |= LGAR_ST_NAN;
-#endif
+      // NaN anywhere in the front table (the reference raises at the pow that produces it, physics/utils.py:17-27).
+      // MODE 1: a NaN depth or theta reaches the column mass just computed, a NaN psi reaches a theta within a step.
+      if constexpr (MODE == 0) {
+        bool bad = false;
+        for (int i = 0; i < nf; i++) bad = bad || is_nan(val(F.TH(i))) || is_nan(val(F.Z(i))) || is_nan(val(F.PS(i)));
+        if (bad) status |= LGAR_ST_NAN;
+      } else {
+        if (is_nan(val(ending_volume_sub))) status |= LGAR_ST_NAN;
+      }
     }
   }
 };

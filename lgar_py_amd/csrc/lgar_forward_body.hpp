@@ -1,0 +1,262 @@
+// lgar_forward_body.hpp -- what ONE lane (= one soil column) of the forward / init kernels does.
+//
+// Kept apart from the __global__ wrappers (lgar_kernels.hip) so that the very same code can be compiled for the host by
+// the test-only device-code simulator (tests/devsim, -DLGAR_DEVSIM: one lane at a time, wave reductions = identity).
+//
+// Front-capacity chain.  The front table of a wave lives in LDS, so a kernel is compiled for a front capacity CAP
+// (LGAR_CAP_SMALL / _MID / _MAX slots per column; the reference's lists are unbounded, layers/Layer.py:1336-1416).
+// lgar_forward launches the smallest capacity that fits n_layers + num_subcycles, and then the larger ones over the SAME
+// arrays: a column that could outgrow its kernel's capacity during the coming forcing step (n_fronts + num_subcycles >
+// CAP: a sub-step creates at most one front) stops BEFORE that step with its state stored, status = LGAR_ST_RESUME and
+// the step index in the status word's upper bits; the next kernel of the chain picks exactly those columns up at that
+// step (waves without such a column exit at once).  Only the last kernel of the chain can report LGAR_ST_OVERFLOW.
+#pragma once
+#include "lgar_device.hpp"
+
+namespace lgar {
+
+template <typename R> struct KArgs {
+  int N, T, F;                                            // columns, forcing steps, rows of the per-front state arrays
+  int chain_first, chain_last;                            // position in the capacity chain (see above)
+  const R *alpha, *n, *ksat, *theta_e, *theta_r, *thick;  // [NL][N]
+  R *depth, *theta, *psi, *k, *dzdt;                      // [F][N]
+  uint8_t *flags;                                         // [F][N]
+  int32_t *nf;                                            // [N]
+  R *scalars;                                             // [NSCAL][N]
+  R *totals;                                              // [NACC][N]
+  const R *precip, *pet;                                  // [T][N]
+  R *series[LGAR_NACC];                                   // [T][N] or null
+  double *basin;                                          // [NACC][T] or null
+  const R *weights;                                       // [N] or null
+  unsigned basin_mask;
+  int32_t *status;                                        // [N]
+  unsigned long long *counters;                           // [LGAR_NCOUNTERS] or null (measurement: Geff wave-calls ...)
+  R *call_sums;                                           // [NACC][N] or null: accumulators summed over this call's steps
+  Glob<R> G;
+};
+
+template <typename S, int FMAX> struct WaveLDS {
+  S f[4][FMAX][WAVE];
+  unsigned char fl[FMAX][WAVE];
+  unsigned geff_calls;  // wave-level count of Geff evaluations (measurement)
+};
+
+#ifndef LGAR_DEVSIM
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+__device__ __forceinline__ void atomic_add(double *p, double v) { atomicAdd(p, v); }
+__device__ __forceinline__ void atomic_add(unsigned long long *p, unsigned long long v) { atomicAdd(p, v); }
+#else
+__device__ __forceinline__ double wave_sum(double v) { return v; }
+__device__ __forceinline__ void atomic_add(double *p, double v) { *p += v; }
+__device__ __forceinline__ void atomic_add(unsigned long long *p, unsigned long long v) { *p += v; }
+#endif
+
+template <typename R, int NL>
+__device__ __forceinline__ void load_params(const KArgs<R> &a, size_t c, ColParams<R, NL> &P) {
+  const size_t N = (size_t)a.N;
+#pragma unroll
+  for (int k = 0; k < NL; k++) {
+    P.alpha[k] = a.alpha[k * N + c];
+    P.n[k] = a.n[k * N + c];
+    P.ksat[k] = a.ksat[k * N + c] * a.G.frozen;  // models/dpLGAR.py:57
+    P.te[k] = a.theta_e[k * N + c];
+    P.tr[k] = a.theta_r[k * N + c];
+    P.thick[k] = a.thick[k * N + c];
+    P.m[k] = R(1.0) - (R(1.0) / P.n[k]);  // calc_m, physics/utils.py:67-69
+    P.inv_m[k] = R(1.0) / P.m[k];
+    P.ninv_m[k] = R(-1.0) / P.m[k];
+    P.inv_n[k] = R(1.0) / P.n[k];
+    P.cum[k] = (k == 0) ? P.thick[0] : P.cum[(k > 0) ? k - 1 : 0] + P.thick[k];  // GlobalParams.py:99-109
+  }
+}
+
+template <typename S> __device__ __forceinline__ FrontsView<S> make_view(S *f, unsigned char *fl, int fmax, int lane) {
+  FrontsView<S> F;
+  F.z = f + 0 * fmax * WAVE + lane;
+  F.th = f + 1 * fmax * WAVE + lane;
+  F.ps = f + 2 * fmax * WAVE + lane;
+  F.dz = f + 3 * fmax * WAVE + lane;
+  F.fl = fl + lane;
+  return F;
+}
+
+// state LDS/registers -> HBM.  Rows [0, nf) are written, rows [nf, nf_before) (fronts that disappeared) are zeroed.
+template <typename R, int NL, int FMAX, int MODE>
+__device__ __forceinline__ void store_state(const KArgs<R> &a, size_t c, const Column<R, NL, FMAX, MODE> &col, int nf_before,
+                                            int status_word) {
+  const size_t N = (size_t)a.N;
+  const int rows = (col.nf > nf_before ? col.nf : nf_before) < a.F ? (col.nf > nf_before ? col.nf : nf_before) : a.F;
+  for (int i = 0; i < rows; i++) {
+    const bool live = i < col.nf;
+    a.depth[i * N + c] = live ? col.F.Z(i) : R(0);
+    a.theta[i * N + c] = live ? col.F.TH(i) : R(0);
+    a.psi[i * N + c] = live ? col.F.PS(i) : R(0);
+    a.k[i * N + c] = live ? ((i < col.nf - 1) ? col.front_k(i, pick(col.P, col.F.layer(i))) : col.k_deepest) : R(0);
+    a.dzdt[i * N + c] = live ? col.F.DZ(i) : R(0);
+    a.flags[i * N + c] = live ? col.F.fl[i * WAVE] : (uint8_t)0;
+  }
+  a.nf[c] = col.nf;
+  a.scalars[0 * N + c] = col.ponded_water;
+  a.scalars[1 * N + c] = col.previous_precip;
+  a.scalars[2 * N + c] = col.ending_volume;
+#pragma unroll
+  for (int i = 0; i < LGAR_GMAX; i++) a.scalars[(3 + i) * N + c] = col.giuh_q[i];
+  a.status[c] = status_word;
+}
+
+// dpLGAR.set_internal_states (models/dpLGAR.py:97-147) for one column
+template <typename R, int NL, int FMAX>
+__device__ __forceinline__ void init_lane(const KArgs<R> &a, size_t c, int lane, WaveLDS<R, FMAX> &lds) {
+  ColParams<R, NL> P;
+  load_params<R, NL>(a, c, P);
+  Column<R, NL, FMAX, 1> col(P, a.G, make_view<R>(&lds.f[0][0][0], &lds.fl[0][0], FMAX, lane));
+  col.init_state();
+  const int nf_before = a.nf[c];
+  store_state<R, NL, FMAX, 1>(a, c, col, nf_before < 0 ? 0 : nf_before, 0);
+  const size_t N = (size_t)a.N;
+#pragma unroll
+  for (int j = 0; j < LGAR_NACC; j++) a.totals[j * N + c] = (j == 9) ? col.ending_volume : R(0);
+}
+
+// T x (dpLGAR.forward + MassBalance.change_mass) for one column; the time loop is inside.
+// `live` = false for the padding lanes of a ragged tail wave: they integrate a copy of the last column (all 64 lanes stay
+// active for the wave reductions) and store nothing.
+template <typename R, int NL, int FMAX, int MODE>
+__device__ __forceinline__ void forward_lane(const KArgs<R> &a, size_t c, bool live, int lane, WaveLDS<R, FMAX> &lds) {
+  const size_t N = (size_t)a.N;
+  const bool basin_on = (a.basin != nullptr) && (a.basin_mask != 0u);
+  int status = a.status[c];
+  // which step this lane starts at: 0 in the first kernel of the chain, the recorded step for a column handed over by
+  // the previous kernel, never (T) for everybody else in a later kernel
+  int t_begin = 0;
+  if (!a.chain_first) {
+    t_begin = (status & LGAR_ST_RESUME) ? (int)((unsigned)status >> LGAR_ST_STEP_SHIFT) : a.T;
+    if (any_lane(t_begin < a.T) == 0ull) return;  // nothing handed over to this wave
+  }
+  status &= LGAR_ST_FAULT_MASK;
+  const bool mine = t_begin < a.T;
+  ColParams<R, NL> P;
+  load_params<R, NL>(a, c, P);
+  Column<R, NL, FMAX, MODE> col(P, a.G, make_view<R>(&lds.f[0][0][0], &lds.fl[0][0], FMAX, lane));
+  // state HBM -> LDS / registers
+  const int nf_stored = a.nf[c];
+  const int cap = FMAX < a.F ? FMAX : a.F;
+  int nf = nf_stored < 0 ? 0 : (nf_stored > cap ? cap : nf_stored);
+  const int nf_before = nf;
+  col.nf = nf;
+  for (int i = 0; i < nf; i++) {
+    col.F.Z(i) = a.depth[i * N + c];
+    col.F.TH(i) = a.theta[i * N + c];
+    col.F.PS(i) = a.psi[i * N + c];
+    col.F.DZ(i) = a.dzdt[i * N + c];
+    col.F.fl[i * WAVE] = a.flags[i * N + c];
+  }
+  col.ponded_water = a.scalars[0 * N + c];
+  col.previous_precip = a.scalars[1 * N + c];
+  col.ending_volume = a.scalars[2 * N + c];
+#pragma unroll
+  for (int i = 0; i < LGAR_GMAX; i++) col.giuh_q[i] = a.scalars[(3 + i) * N + c];
+  col.status = status;
+  if (nf < NL) col.status |= LGAR_ST_STRUCT;  // not a state lgar_state_init / lgar_forward produced: column is skipped
+  col.k_deepest = (nf > 0) ? a.k[(size_t)(nf - 1) * N + c] : R(0);
+  col.new_front_frozen = false;
+  col.cap = FMAX < a.F ? FMAX : a.F;
+  col.wave_geff_calls = &lds.geff_calls;
+  if (lane == 0) lds.geff_calls = 0u;
+  col.drain();
+  R tot[8];  // accumulators summed over the steps this kernel integrates
+#pragma unroll
+  for (int j = 0; j < 8; j++) tot[j] = R(0);
+  double wgt = 0.0;
+  if (basin_on) wgt = live ? (a.weights ? (double)a.weights[c] : 1.0) : 0.0;
+
+  bool running = mine;      // false once the column is handed to the next kernel of the chain
+  int t_handover = a.T;
+  bool untouched = false;   // stopped before its first step: the state in HBM is left as it is
+  if (mine && nf_stored > cap) {
+    // more fronts than this kernel can hold: next kernel of the chain, or (last kernel) front overflow
+    running = false;
+    untouched = true;
+    if (a.chain_last) col.status |= LGAR_ST_OVERFLOW; else t_handover = t_begin;
+  }
+  // software prefetch: the next step's forcing is requested before this step is integrated, so its HBM latency
+  // hides under ~10^4 cycles of VALU work
+  R precip_nx = a.T > 0 ? a.precip[c] : R(0);
+  R pet_nx = a.T > 0 ? a.pet[c] : R(0);
+  for (int t = 0; t < a.T; t++) {
+    const size_t o = (size_t)t * N + c;
+    const R precip = precip_nx;
+    const R pet = pet_nx;
+    if (t + 1 < a.T) {
+      precip_nx = a.precip[o + N];
+      pet_nx = a.pet[o + N];
+    }
+    bool active = running && t >= t_begin;
+    if (active && !a.chain_last && col.nf + a.G.nsub > FMAX) {
+      // this step could outgrow the kernel's front capacity: hand the column over, state as of the end of step t-1
+      running = active = false;
+      t_handover = t;
+      untouched = (t == t_begin);
+    }
+    if (any_lane(active) == 0ull) continue;
+    if (active) col.forward(precip, pet);
+    const R acc[LGAR_NACC] = {col.a_precip, col.a_pet, col.a_aet, col.a_infil, col.a_runoff,
+                              col.a_perc, col.a_giuh, col.a_disch, col.ponded_water, col.ending_volume};
+    if (live && active) {
+#pragma unroll
+      for (int j = 0; j < LGAR_NACC; j++)
+        if (a.series[j]) a.series[j][o] = acc[j];
+    }
+    if (basin_on) {
+      // basin aggregation in the epilogue of the step (physics/MassBalance.py:77-108 over many columns)
+      const double w = active ? wgt : 0.0;
+#pragma unroll
+      for (int j = 0; j < LGAR_NACC; j++)
+        if (a.basin_mask & (1u << j)) {
+          const double s = wave_sum(w * (double)acc[j]);
+          if (lane == 0) atomic_add(&a.basin[(size_t)j * a.T + t], s);
+        }
+    }
+    if (active) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) tot[j] = tot[j] + acc[j];  // MassBalance.change_mass, MassBalance.py:31-44
+      col.drain();
+    }
+  }
+  if (a.counters != nullptr) {
+    // measurement: wave-level Geff evaluations (the dominant instruction stream) of this launch
+    if (lane == 0 && lds.geff_calls) atomic_add(&a.counters[0], (unsigned long long)lds.geff_calls);
+  }
+  if (!live || !mine) return;
+  int word = col.status;
+  if (t_handover < a.T) word |= LGAR_ST_RESUME | (int)((unsigned)t_handover << LGAR_ST_STEP_SHIFT);
+  if (untouched) {
+    a.status[c] = word;
+    if (a.call_sums != nullptr && a.chain_first) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) a.call_sums[j * N + c] = R(0);
+      a.call_sums[8 * N + c] = col.ponded_water;
+      a.call_sums[9 * N + c] = col.ending_volume;
+    }
+    return;
+  }
+  store_state<R, NL, FMAX, MODE>(a, c, col, nf_before, word);
+#pragma unroll
+  for (int j = 0; j < 8; j++) a.totals[j * N + c] = a.totals[j * N + c] + tot[j];  // MassBalance's run totals
+  a.totals[8 * N + c] = col.ponded_water;
+  a.totals[9 * N + c] = col.ending_volume;
+  if (a.call_sums != nullptr) {
+    // a column handed over by an earlier kernel of the chain already has its first part in place
+    const bool add = !a.chain_first;
+#pragma unroll
+    for (int j = 0; j < 8; j++) a.call_sums[j * N + c] = add ? a.call_sums[j * N + c] + tot[j] : tot[j];
+    a.call_sums[8 * N + c] = col.ponded_water;
+    a.call_sums[9 * N + c] = col.ending_volume;
+  }
+}
+
+}  // namespace lgar

@@ -17,20 +17,23 @@ template <typename R> inline Glob<R> make_glob(const LgarDims *d) {
   G.nint = d->nint;
   G.nsub = d->num_subcycles;
   G.ng = d->n_giuh;
-  G.search_mode = d->search_mode;
   G.bottom_mode = d->bottom_mode;
   G.closed_form = d->use_closed_form_G;
-  // literal searches (mode 0) are unbounded in the reference: generous cap.  In mode 1 the depth search needs a few
-  // dozen iterations when it converges at all, so a diverging column (reference: endless loop) is cut off early.
+  // literal searches (mode 0) are unbounded in the reference: generous cap.  In the fast modes the depth search needs a
+  // few dozen iterations when it converges at all, so a diverging column (reference: endless loop) is cut off early.
   G.iter_cap = d->iter_cap > 0 ? d->iter_cap : (d->search_mode != 0 ? 5000LL : 2000000LL);
   return G;
 }
+
+inline int front_slots(const LgarDims *d) { return d->front_slots > 0 ? d->front_slots : LGAR_FMAX; }
 
 inline int check_dims(const LgarDims *d) {
   if (!d) return LGAR_E_ARG;
   if (d->n_columns <= 0 || d->n_layers < LGAR_LMIN || d->n_layers > LGAR_LMAX) return LGAR_E_ARG;
   if (d->n_giuh < 0 || d->n_giuh > LGAR_GMAX) return LGAR_E_ARG;
-  if (d->nint <= 0 || d->num_subcycles <= 0 || d->n_steps < 0) return LGAR_E_ARG;
+  if (d->nint <= 0 || d->num_subcycles <= 0 || d->n_steps < 0 || d->n_steps >= (1 << 23)) return LGAR_E_ARG;
+  if (d->search_mode < 0 || d->search_mode > 2) return LGAR_E_ARG;
+  if (d->front_slots < 0 || d->front_slots > LGAR_FMAX || (d->front_slots > 0 && d->front_slots < d->n_layers + 1)) return LGAR_E_ARG;
   if (!(d->dt_h > 0.0)) return LGAR_E_ARG;
   return 0;
 }

@@ -1,0 +1,143 @@
+// lgar_kernels_nl.hip -- gfx950 forward / init kernels for ONE soil-layer count (compiled with -DLGAR_NL=<n>).
+//
+// Launch geometry: one 64-thread workgroup == one wavefront == 64 soil columns; a grid of ceil(N/64) workgroups
+// (>> 256 CUs for the 1M-column configs).  One-wave workgroups keep the LDS allocation per wave, so the number of
+// resident waves per CU is set by LDS (front tables) and VGPRs alone, and no barrier is ever needed: lanes never share
+// data.  Occupancy by front capacity (fp32): 8 slots = 8.7 KB LDS/wave and <= 128 VGPRs -> 4 waves/SIMD, which also
+// makes the 1M-column grid (16 384 waves) exactly 4 rounds of the chip's 4 096 wave slots; 16 / 32 slots serve the
+// (rare) columns handed over by the capacity chain (lgar_forward_body.hpp).
+//
+// HBM traffic per launch (all coalesced, column-fastest): parameters 6*L*N, front state 2*(5*n_fronts+1)*N,
+// scalars/totals, and per forcing step 2 loads + (number of requested series) stores per column.
+#include <hip/hip_runtime.h>
+
+#include "lgar_forward_body.hpp"
+#include "lgar_host.hpp"
+#include "lgar_launch.hpp"
+
+#ifndef LGAR_NL
+#error "compile with -DLGAR_NL=<number of soil layers>"
+#endif
+
+namespace lgar {
+
+// waves per SIMD the register allocator has to make room for
+template <typename R, int CAP> struct Occupancy {
+  static constexpr int waves = (sizeof(R) == 4) ? ((CAP <= LGAR_CAP_SMALL) ? 4 : ((CAP <= LGAR_CAP_MID) ? 2 : 1))
+                                                : ((CAP <= LGAR_CAP_SMALL) ? 2 : 1);
+};
+
+template <typename R, int NL, int CAP>
+__global__ __launch_bounds__(WAVE) void lgar_init_kernel(KArgs<R> a) {
+  __shared__ WaveLDS<R, CAP> lds;
+  const int lane = threadIdx.x;
+  const size_t c = (size_t)blockIdx.x * WAVE + lane;
+  if (c >= (size_t)a.N) return;
+  init_lane<R, NL, CAP>(a, c, lane, lds);
+}
+
+template <typename R, int NL, int CAP, int MODE>
+__global__ __launch_bounds__(WAVE, (Occupancy<R, CAP>::waves)) void lgar_forward_kernel(KArgs<R> a) {
+  __shared__ WaveLDS<R, CAP> lds;
+  const int lane = threadIdx.x;
+  const size_t N = (size_t)a.N;
+  const size_t c0 = (size_t)blockIdx.x * WAVE + lane;
+  const bool live = c0 < N;
+  forward_lane<R, NL, CAP, MODE>(a, live ? c0 : N - 1, live, lane, lds);
+}
+
+template <typename R>
+static KArgs<R> make_args(const LgarDims *d, const LgarParams *p, LgarState *s, const LgarForcing *f, const LgarStepOut *o,
+                          int32_t *status) {
+  KArgs<R> a;
+  a.N = d->n_columns;
+  a.T = d->n_steps;
+  a.F = front_slots(d);
+  a.chain_first = a.chain_last = 1;
+  a.alpha = (const R *)p->alpha; a.n = (const R *)p->n; a.ksat = (const R *)p->ksat;
+  a.theta_e = (const R *)p->theta_e; a.theta_r = (const R *)p->theta_r; a.thick = (const R *)p->thickness;
+  a.depth = (R *)s->depth; a.theta = (R *)s->theta; a.psi = (R *)s->psi; a.k = (R *)s->k; a.dzdt = (R *)s->dzdt;
+  a.flags = s->flags;
+  a.nf = s->n_fronts;
+  a.scalars = (R *)s->scalars;
+  a.totals = (R *)s->totals;
+  a.precip = f ? (const R *)f->precip : nullptr;
+  a.pet = f ? (const R *)f->pet : nullptr;
+  for (int j = 0; j < LGAR_NACC; j++) a.series[j] = o ? (R *)o->series[j] : nullptr;
+  a.basin = o ? o->basin : nullptr;
+  a.basin_mask = o ? o->basin_mask : 0u;
+  a.weights = o ? (const R *)o->weights : nullptr;
+  a.counters = o ? (unsigned long long *)o->counters : nullptr;
+  a.call_sums = o ? (R *)o->call_sums : nullptr;
+  a.status = status;
+  a.G = make_glob<R>(d);
+  return a;
+}
+
+template <typename R, int NL>
+static int init_typed(const LgarDims *dims, const LgarParams *params, LgarState *state, int32_t *status, hipStream_t st) {
+  const unsigned grid = (unsigned)((dims->n_columns + WAVE - 1) / WAVE);
+  KArgs<R> a = make_args<R>(dims, params, state, nullptr, nullptr, status);
+  hipLaunchKernelGGL((lgar_init_kernel<R, NL, LGAR_CAP_SMALL>), dim3(grid), dim3(WAVE), 0, st, a);
+  return launch_status();
+}
+
+// The front-capacity chain of one lgar_forward call (see lgar_forward_body.hpp).
+template <typename R, int NL>
+static int forward_typed(const LgarDims *dims, const LgarParams *params, LgarState *state, const LgarForcing *forcing,
+                         const LgarStepOut *out, int32_t *status, hipStream_t st) {
+  const unsigned grid = (unsigned)((dims->n_columns + WAVE - 1) / WAVE);
+  KArgs<R> a = make_args<R>(dims, params, state, forcing, out, status);
+  const int slots = a.F;
+  if (dims->search_mode == 0) {
+    // the reference's literal searches: verification mode, one kernel at the full capacity
+    hipLaunchKernelGGL((lgar_forward_kernel<R, NL, LGAR_FMAX, 0>), dim3(grid), dim3(WAVE), 0, st, a);
+    return launch_status();
+  }
+  // smallest capacity that leaves room for a forcing step (one front per layer + one new front per sub-step + slack);
+  // small jobs (under one wave per SIMD) gain nothing from occupancy and start at the full capacity
+  const int need = NL + dims->num_subcycles + 2;
+  const bool tiny = grid <= 1024u && dims->search_mode != 2;  // search_mode 2: chain forced (tests)
+  int caps[3], nc = 0;
+  if (!tiny && need <= LGAR_CAP_SMALL && slots > LGAR_CAP_SMALL) caps[nc++] = LGAR_CAP_SMALL;
+  if (!tiny && need <= LGAR_CAP_MID && slots > LGAR_CAP_MID) caps[nc++] = LGAR_CAP_MID;
+  caps[nc++] = LGAR_FMAX;
+  for (int i = 0; i < nc; i++) {
+    a.chain_first = (i == 0);
+    a.chain_last = (i == nc - 1);
+    switch (caps[i]) {
+      case LGAR_CAP_SMALL:
+        hipLaunchKernelGGL((lgar_forward_kernel<R, NL, LGAR_CAP_SMALL, 1>), dim3(grid), dim3(WAVE), 0, st, a);
+        break;
+      case LGAR_CAP_MID:
+        hipLaunchKernelGGL((lgar_forward_kernel<R, NL, LGAR_CAP_MID, 1>), dim3(grid), dim3(WAVE), 0, st, a);
+        break;
+      default:
+        hipLaunchKernelGGL((lgar_forward_kernel<R, NL, LGAR_FMAX, 1>), dim3(grid), dim3(WAVE), 0, st, a);
+        break;
+    }
+    const int rc = launch_status();
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+template <int NL>
+int launch_init_nl(const LgarDims *dims, const LgarParams *params, LgarState *state, int32_t *status, int dtype, hipStream_t st) {
+  if (dtype == LGAR_F64) return init_typed<double, NL>(dims, params, state, status, st);
+  if (dtype == LGAR_F32) return init_typed<float, NL>(dims, params, state, status, st);
+  return LGAR_E_ARG;
+}
+template <int NL>
+int launch_forward_nl(const LgarDims *dims, const LgarParams *params, LgarState *state, const LgarForcing *forcing,
+                      const LgarStepOut *out, int32_t *status, int dtype, hipStream_t st) {
+  if (dtype == LGAR_F64) return forward_typed<double, NL>(dims, params, state, forcing, out, status, st);
+  if (dtype == LGAR_F32) return forward_typed<float, NL>(dims, params, state, forcing, out, status, st);
+  return LGAR_E_ARG;
+}
+
+template int launch_init_nl<LGAR_NL>(const LgarDims *, const LgarParams *, LgarState *, int32_t *, int, hipStream_t);
+template int launch_forward_nl<LGAR_NL>(const LgarDims *, const LgarParams *, LgarState *, const LgarForcing *,
+                                        const LgarStepOut *, int32_t *, int, hipStream_t);
+
+}  // namespace lgar

@@ -5,7 +5,9 @@
 // pow for the exponents used here) in ~20-30 instructions: frexp + atanh series for log2, round-to-nearest + Taylor +
 // ldexp for exp2.  That is nine orders of magnitude inside the 1e-6 parity bar; -DLGAR_F64_LIBM restores ocml.
 #pragma once
+#ifndef LGAR_DEVSIM
 #include <hip/hip_runtime.h>
+#endif
 
 namespace lgar {
 
@@ -41,7 +43,11 @@ __device__ __forceinline__ double fast_log2(double x) {
   e = lo ? e - 1 : e;
   // (m - 1) / (m + 1) with v_rcp_f64 + one Newton step instead of the ~12-instruction IEEE divide
   const double d = m + 1.0;
+#ifndef LGAR_DEVSIM
   double rc = __builtin_amdgcn_rcp(d);
+#else
+  double rc = 1.0 / d;
+#endif
   rc = fma(fma(-d, rc, 1.0), rc, rc);
   const double s = (m - 1.0) * rc;  // |s| <= 0.1716
   const double z = s * s;

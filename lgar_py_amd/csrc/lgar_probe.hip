@@ -118,41 +118,30 @@ template <int OP> __device__ __forceinline__ void probe_body(float (&v)[8], f32x
     REP64(X)
 #undef X
   } else if (OP == LGAR_PROBE_GEFF_MIX) {
-    // the instruction mix of one packed Geff iteration (two trapezoid nodes): 4 v_log + 6 v_exp + 12 packed + 10 plain,
-    // repeated twice = 64 instructions
-#define NODEPAIR(a, b)                                                                             \
-    asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[a]) : "v"(p[b]));                                 \
-    asm volatile("v_log_f32 %0, %0" : "+v"(v[a]));                                                    \
-    asm volatile("v_log_f32 %0, %0" : "+v"(v[b]));                                                    \
-    asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[a + 1]) : "v"(p[b]));                             \
-    asm volatile("v_exp_f32 %0, %0" : "+v"(v[a]));                                                    \
-    asm volatile("v_exp_f32 %0, %0" : "+v"(v[b]));                                                    \
-    asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[a]) : "v"(p[b + 1]));                             \
-    asm volatile("v_log_f32 %0, %0" : "+v"(v[a + 1]));                                                \
-    asm volatile("v_log_f32 %0, %0" : "+v"(v[b + 1]));                                                \
-    asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[a + 1]) : "v"(p[b + 1]));                         \
-    asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[a]) : "v"(p[b]));                                 \
-    asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[a + 1]) : "v"(p[b]));                             \
-    asm volatile("v_exp_f32 %0, %0" : "+v"(v[a]));                                                    \
-    asm volatile("v_exp_f32 %0, %0" : "+v"(v[b]));                                                    \
-    asm volatile("v_exp_f32 %0, %0" : "+v"(v[a + 1]));                                                \
-    asm volatile("v_exp_f32 %0, %0" : "+v"(v[b + 1]));                                                \
-    asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[a]) : "v"(p[b + 1]));                             \
-    asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[a + 1]) : "v"(p[b + 1]));                         \
-    asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[a]) : "v"(p[b]));                                 \
-    asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[a + 1]) : "v"(p[b]));                             \
-    asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(p[a]) : "v"(p[b]));                             \
-    asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(p[a + 1]) : "v"(p[b + 1]));                     \
-    asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(v[a]), "v"(c) : "vcc");                           \
-    asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(v[a]) : "v"(c));                              \
-    asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(v[b]), "v"(c) : "vcc");                           \
-    asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(v[b]) : "v"(c));                              \
-    asm volatile("v_add_f32 %0, %0, %1" : "+v"(v[a + 1]) : "v"(v[a]));                                \
-    asm volatile("v_mul_f32 %0, %0, %1" : "+v"(v[a + 1]) : "v"(c));                                   \
-    asm volatile("v_add_f32 %0, %0, %1" : "+v"(v[b + 1]) : "v"(v[b]));                                \
-    asm volatile("v_mul_f32 %0, %0, %1" : "+v"(v[b + 1]) : "v"(c));                                   \
-    asm volatile("v_add_f32 %0, %0, %1" : "+v"(v[a]) : "v"(v[a + 1]));                                \
-    asm volatile("v_add_f32 %0, %0, %1" : "+v"(v[b]) : "v"(v[b + 1]));
+    // the instruction stream of one iteration of the lean fp32 Geff loop (lgar_device.hpp geff<float>: two trapezoid
+    // nodes): 4 v_log + 4 v_exp + 3 v_pk_fma + 5 v_pk_mul + 2 v_pk_add, in program order with its dependences; four node
+    // pairs = 72 instructions per probe iteration
+#define NODEPAIR(a, b)                                                                                 \
+    asm volatile("v_pk_fma_f32 %0, %1, %1, %0" : "+v"(p[a]) : "v"(p[b]));                                 \
+    asm volatile("v_log_f32 %0, %1" : "=v"(v[a]) : "v"(p[a].x));                                          \
+    asm volatile("v_log_f32 %0, %1" : "=v"(v[b]) : "v"(p[a].y));                                          \
+    asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[b]) : "v"(p[a]));                                     \
+    asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[a]) : "v"(p[b]));                                     \
+    asm volatile("v_exp_f32 %0, %0" : "+v"(v[a]));                                                        \
+    asm volatile("v_exp_f32 %0, %0" : "+v"(v[b]));                                                        \
+    asm volatile("v_pk_fma_f32 %0, %1, %1, %0" : "+v"(p[a]) : "v"(p[b]));                                 \
+    asm volatile("v_log_f32 %0, %0" : "+v"(v[a]));                                                        \
+    asm volatile("v_log_f32 %0, %0" : "+v"(v[b]));                                                        \
+    asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[a]) : "v"(p[b]));                                     \
+    asm volatile("v_exp_f32 %0, %0" : "+v"(v[a]));                                                        \
+    asm volatile("v_exp_f32 %0, %0" : "+v"(v[b]));                                                        \
+    asm volatile("v_pk_mul_f32 %0, %0, %0" : "+v"(p[a]));                                                 \
+    asm volatile("v_pk_fma_f32 %0, %1, %1, %0" : "+v"(p[a]) : "v"(p[b]));                                 \
+    asm volatile("v_pk_mul_f32 %0, %0, %0" : "+v"(p[a]));                                                 \
+    asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[a]) : "v"(p[b]));                                     \
+    asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[b + 1]) : "v"(p[a]));
+    NODEPAIR(0, 2)
+    NODEPAIR(4, 6)
     NODEPAIR(0, 2)
     NODEPAIR(4, 6)
 #undef NODEPAIR
@@ -182,6 +171,8 @@ template <int OP> __global__ __launch_bounds__(64) void lgar_probe_kernel(int it
 }  // namespace lgar
 
 using namespace lgar;
+
+extern "C" int32_t lgar_valu_probe_insts(int32_t op) { return op == LGAR_PROBE_GEFF_MIX ? 72 : 64; }
 
 extern "C" int32_t lgar_valu_probe(int32_t op, int32_t n_workgroups, int32_t lds_bytes_per_workgroup, int32_t iters,
                                    void *sink, void *stream) {

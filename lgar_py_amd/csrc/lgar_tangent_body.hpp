@@ -1,0 +1,76 @@
+// lgar_tangent_body.hpp -- what one lane of the forward-mode tangent kernels does (the differentiable path).
+//
+// Same device physics as the forward kernels, instantiated with Dual<R> (lgar_dual.hpp).  One launch integrates value +
+// tangent for ONE parameter direction applied to every column's own parameters (columns are independent, so a one-hot
+// direction over (alpha|n|Ksat, layer) yields every column's partial derivative at once) and contracts
+// d runoff_t / d percolation_t with the caller's weights (the incoming gradient) on the fly: nothing is stored per step.
+// A vector-Jacobian product over the 3 x L parameters is 3 x L such launches.
+//
+// Front capacity: values + tangents double the LDS per front, so the first kernel runs with LGAR_CAP_SMALL slots; a
+// column that could outgrow them is flagged LGAR_ST_RESUME and the second kernel (LGAR_FMAX slots) integrates exactly
+// those columns again from their fresh state (a tangent run always starts from set_internal_states).
+#pragma once
+#include "lgar_dual.hpp"
+#include "lgar_forward_body.hpp"
+
+namespace lgar {
+
+template <typename R> struct TArgs {
+  int N, T;
+  int chain_first, chain_last;
+  const R *alpha, *n, *ksat, *theta_e, *theta_r, *thick;  // [NL][N]
+  const R *d_alpha, *d_n, *d_ksat;                        // [NL][N] or null
+  const R *precip, *pet;                                  // [T][N]
+  const R *w_runoff, *w_perc;                             // [T][N] or null
+  R *grad_out;                                            // [N]
+  R *tangent_runoff;                                      // [T][N] or null
+  int32_t *status;                                        // [N]
+  Glob<R> G;
+};
+
+template <typename R, int NL, int FMAX, int MODE>
+__device__ __forceinline__ void tangent_lane(const TArgs<R> &a, size_t c, int lane, WaveLDS<Dual<R>, FMAX> &lds) {
+  using S = Dual<R>;
+  const size_t N = (size_t)a.N;
+  if (!a.chain_first) {
+    const bool mine = (a.status[c] & LGAR_ST_RESUME) != 0;
+    if (any_lane(mine) == 0ull) return;
+    if (!mine) return;  // lanes share nothing in this kernel: no wave-level operation follows
+  }
+  ColParams<S, NL> P;
+#pragma unroll
+  for (int k = 0; k < NL; k++) {
+    const size_t o = k * N + c;
+    P.alpha[k] = S(a.alpha[o], a.d_alpha ? a.d_alpha[o] : R(0));
+    P.n[k] = S(a.n[o], a.d_n ? a.d_n[o] : R(0));
+    P.ksat[k] = S(a.ksat[o], a.d_ksat ? a.d_ksat[o] : R(0)) * a.G.frozen;  // models/dpLGAR.py:57
+    P.te[k] = S(a.theta_e[o]);
+    P.tr[k] = S(a.theta_r[o]);
+    P.thick[k] = S(a.thick[o]);
+    P.m[k] = R(1.0) - (R(1.0) / P.n[k]);
+    P.inv_m[k] = R(1.0) / P.m[k];
+    P.ninv_m[k] = R(-1.0) / P.m[k];
+    P.inv_n[k] = R(1.0) / P.n[k];
+    P.cum[k] = (k == 0) ? P.thick[0] : P.cum[(k > 0) ? k - 1 : 0] + P.thick[k];
+  }
+  Column<S, NL, FMAX, MODE> col(P, a.G, make_view<S>(&lds.f[0][0][0], &lds.fl[0][0], FMAX, lane));
+  col.init_state();
+  R grad = R(0);
+  bool handed_over = false;
+  for (int t = 0; t < a.T; t++) {
+    const size_t o = (size_t)t * N + c;
+    if (!a.chain_last && col.nf + a.G.nsub > FMAX) {
+      handed_over = true;  // could outgrow this kernel's front capacity: the next kernel redoes this column
+      break;
+    }
+    col.forward(S(a.precip[o]), S(a.pet[o]));
+    if (a.w_runoff) grad += a.w_runoff[o] * col.a_runoff.d;
+    if (a.w_perc) grad += a.w_perc[o] * col.a_perc.d;
+    if (a.tangent_runoff) a.tangent_runoff[o] = col.a_runoff.d;
+    col.drain();
+  }
+  a.grad_out[c] = handed_over ? R(0) : grad;
+  a.status[c] = handed_over ? (col.status | LGAR_ST_RESUME) : col.status;
+}
+
+}  // namespace lgar

@@ -72,16 +72,55 @@ def tile_forcing(x, n_columns, scale=None, device="cuda:0", dtype=torch.float64)
     return precip, pet
 
 
+def read_observations(path, nsteps=None, column=None):
+    """Observation series of cfg.data.observations (data/Data.py:59-65 reads the `total_precipitation` column of that
+    CSV): `column` if given, else `total_precipitation`, else the first numeric column that is not the time stamp.
+    Values are taken as they are (the reference applies no unit conversion)."""
+    with open(path, newline="") as f:
+        rd = csv.reader(f)
+        header = [h.strip().lstrip("#") for h in next(rd)]
+        rows = [r for r in rd if r and "".join(r).strip()]
+    if column is None:
+        column = "total_precipitation" if "total_precipitation" in header else None
+    if column is not None:
+        if column not in header:
+            raise ValueError("observations file %s has no column %r (columns: %s)" % (path, column, header))
+        j = header.index(column)
+    else:
+        j = None
+        for c, nm in enumerate(header):
+            if nm.lower() in ("time", "date", "datetime"):
+                continue
+            try:
+                float(rows[0][c])
+                j = c
+                break
+            except (ValueError, IndexError):
+                continue
+        if j is None:
+            raise ValueError("observations file %s has no numeric column" % path)
+    vals = np.array([float(r[j]) for r in rows[: nsteps if nsteps is not None else len(rows)]])
+    return vals
+
+
 class Data(torch.utils.data.Dataset):
-    """Counterpart of dpLGAR.data.Data (data/Data.py:22-57): (x[2], y) per forcing row; y are observations if
-    cfg.data.observations is given, else zeros (the reference fills them with torch.rand, Data.py:43)."""
+    """Counterpart of dpLGAR.data.Data (data/Data.py:22-57): (x[2], y) per forcing row.  y holds the observations of
+    cfg.data.observations when that key names a file (optional cfg.data.observation_column), else zeros -- the reference
+    has its read_observations call commented out and trains against torch.rand (Data.py:42-43)."""
 
     def __init__(self, cfg):
         super().__init__()
         self.times, x = read_forcing(cfg.data.forcing_file, cfg.models.nsteps, cfg.conversions.mm_to_cm)
         self.x = torch.tensor(x, dtype=torch.float64)
         self.timestep_map = dict(enumerate(self.times))
-        self.y = torch.zeros(self.x.shape[0], dtype=torch.float64)
+        obs = cfg.data.get("observations") if hasattr(cfg.data, "get") else getattr(cfg.data, "observations", None)
+        if obs:
+            y = read_observations(obs, self.x.shape[0], cfg.data.get("observation_column") if hasattr(cfg.data, "get") else None)
+            if len(y) < self.x.shape[0]:
+                raise ValueError("observations file %s has %d rows, the forcing has %d" % (obs, len(y), self.x.shape[0]))
+            self.y = torch.tensor(y, dtype=torch.float64)
+        else:
+            self.y = torch.zeros(self.x.shape[0], dtype=torch.float64)
 
     def __getitem__(self, i):
         return self.x[i], self.y[i]
@@ -93,4 +132,7 @@ class Data(torch.utils.data.Dataset):
 def calculate_nse(modeled, observed):
     """Nash-Sutcliffe efficiency (data/metrics.py:4-8)."""
     modeled, observed = np.asarray(modeled), np.asarray(observed)
-    return 1 - np.sum((observed - modeled) ** 2) / np.sum((observed - observed.mean()) ** 2)
+    var = np.sum((observed - observed.mean()) ** 2)
+    if var == 0.0:  # constant observations (e.g. none given): NSE is undefined
+        return float("nan")
+    return 1 - np.sum((observed - modeled) ** 2) / var

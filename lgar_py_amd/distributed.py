@@ -17,6 +17,18 @@ def world_info():
     return 0, 1
 
 
+def _all_reduce(t, group=None):
+    """all-reduce(SUM) in place.  RCCL ("nccl") reduces device tensors over xGMI; with the gloo backend (CPU tests, and
+    the rehearsal of several ranks on one GPU) a device tensor goes through the host."""
+    if dist.get_backend(group) == "gloo" and t.is_cuda:
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
 def basin_runoff(local_series, weights=None, group=None):
     """local_series: [T, n_local] per-step runoff of this rank's columns (any float dtype, any device).
     Returns the basin total per timestep [T] in fp64, summed over every rank's columns
@@ -26,14 +38,14 @@ def basin_runoff(local_series, weights=None, group=None):
         s = s * weights.to(torch.float64)[None, :]
     total = s.sum(dim=1)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
+        _all_reduce(total, group)
     return total
 
 
 def all_reduce_sum(t, group=None):
     """In-place all-reduce(SUM) of an already locally reduced tensor (e.g. the kernel's in-epilogue basin sums [T])."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        _all_reduce(t, group)
     return t
 
 
@@ -41,7 +53,7 @@ def reduce_parameter_gradients(grads, group=None):
     """Shared-parameter training: all-reduce(SUM) of the [L x 3] gradient scalars."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         flat = torch.cat([g.reshape(-1) for g in grads])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        _all_reduce(flat, group)
         o = 0
         for g in grads:
             g.copy_(flat[o:o + g.numel()].reshape(g.shape))

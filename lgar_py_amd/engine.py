@@ -26,7 +26,11 @@ class LgarEngine:
 
     Parameters are [L] (shared by all columns) or [L, N] tensors/sequences; forcing is [T, N] (cm/h).
     search_mode: 1 (default) = bracketed-Newton psi search + closed-form jumps in the depth search (same roots, same
-    tolerances); 0 = the reference's literal fixed-step line searches (Layer.py:275-317, 681-701).
+    tolerances); 0 = verification mode: the reference's literal fixed-step line searches (Layer.py:275-317, 681-701),
+    its update_psi pass and, in fp64, its trapezoid operation by operation; 2 = like 1 with the front-capacity chain
+    (8 -> 16 -> 32 slots, include/lgar.h) forced even for small jobs (tests).
+    front_slots: rows of the per-front state arrays = the most fronts a column can hold (<= 32; the reference's lists are
+    unbounded, Layer.py:1336-1416).
     bottom_mode: 0 (default) = like the reference, a front reaching the domain bottom faults the column; 1 = it leaves
     the column as percolation (LGAR-C intent; parity unpinned, the reference crashes there).
     """
@@ -34,7 +38,7 @@ class LgarEngine:
     def __init__(self, alpha, n, ksat, theta_e, theta_r, thickness, *, n_columns=None, dt_h=1.0, num_subcycles=1,
                  initial_psi=2000.0, ponded_depth_max=0.0, wilting_point_psi=15495.0, frozen_factor=1.0, nint=120,
                  giuh_ordinates=(0.06, 0.51, 0.28, 0.12, 0.03), dtype=torch.float64, device="cuda:0",
-                 iter_cap=0, search_mode=1, bottom_mode=0, use_closed_form_G=False):
+                 iter_cap=0, search_mode=1, bottom_mode=0, use_closed_form_G=False, front_slots=None):
         self.device = torch.device(device)
         _require_gpu(self.device)
         self.lib = _capi.load()
@@ -81,8 +85,12 @@ class LgarEngine:
         d.iter_cap = int(iter_cap)
         d.bottom_mode = int(bottom_mode)
         d.use_closed_form_G = int(bool(use_closed_form_G))
+        FMAX = int(front_slots) if front_slots else _capi.FMAX
+        if not L + 1 <= FMAX <= _capi.FMAX:
+            raise LgarError("front_slots must be in %d..%d" % (L + 1, _capi.FMAX))
+        d.front_slots = FMAX
+        self.front_slots = FMAX
 
-        FMAX = _capi.FMAX
         z = lambda *shape, dt=dtype: torch.zeros(*shape, dtype=dt, device=self.device)
         self.depth, self.theta, self.psi = z(FMAX, N), z(FMAX, N), z(FMAX, N)
         self.k, self.dzdt = z(FMAX, N), z(FMAX, N)
@@ -91,6 +99,7 @@ class LgarEngine:
         self.scalars = z(NSCAL, N)
         self.totals = z(NACC, N)
         self.status = z(N, dt=torch.int32)
+        self.counters = z(_capi.NCOUNTERS, dt=torch.int64)
 
         self._params = _capi.LgarParams(*[t.data_ptr() for t in (self.alpha, self.n, self.ksat, self.theta_e,
                                                                  self.theta_r, self.thickness)])
@@ -109,13 +118,15 @@ class LgarEngine:
                                           self.status.data_ptr(), self._dt, self._stream())
         _capi.check(rc, "lgar_state_init")
 
-    def forward(self, precip, pet, series=("runoff", "percolation"), out=None, check=True, basin=(), weights=None):
+    def forward(self, precip, pet, series=("runoff", "percolation"), out=None, check=True, basin=(), weights=None,
+                call_sums=False):
         """Advance every column by T forcing steps.  precip/pet: [T, N] cm/h on self.device.
 
         Returns {name: tensor[T, N]} for the requested per-step series (the model accumulators as they
         stand after each forward(), before MassBalance.change_mass zeroes them).  basin: names whose per-step sum over
         this engine's columns (optionally weighted by weights[N]) is reduced inside the kernel; returned under
-        "basin:<name>" as fp64 [T] tensors."""
+        "basin:<name>" as fp64 [T] tensors.  call_sums=True adds "call_sums": [NACC, N], the accumulators summed over this
+        call's steps (rows 8, 9: latest ponded_water / ending_volume)."""
         precip = torch.as_tensor(precip).to(self.device, self.dtype).contiguous()
         pet = torch.as_tensor(pet).to(self.device, self.dtype).contiguous()
         if precip.dim() == 1:
@@ -145,6 +156,10 @@ class LgarEngine:
                 if tuple(w.shape) != (self.N,):
                     raise LgarError("weights must be [N]")
                 so.weights = w.data_ptr()
+        so.counters = self.counters.data_ptr()
+        if call_sums:
+            res["call_sums"] = torch.zeros(NACC, self.N, dtype=self.dtype, device=self.device)
+            so.call_sums = res["call_sums"].data_ptr()
         self.dims.n_steps = T
         fo = _capi.LgarForcing(precip.data_ptr(), pet.data_ptr())
         with torch.cuda.device(self.device):
@@ -160,9 +175,15 @@ class LgarEngine:
 
         direction: {"alpha" | "n" | "ksat": [L, N] tensor} -- the parameter perturbation (missing = 0).
         Returns (grad[N], tangent_runoff[T, N] or None, status[N]) with
-        grad[c] = sum_t w_runoff[t, c] * d runoff_t[c] + w_perc[t, c] * d percolation_t[c]."""
+        grad[c] = sum_t w_runoff[t, c] * d runoff_t[c] + w_perc[t, c] * d percolation_t[c].  status != 0 marks columns whose
+        tangent integration faulted (their grad entry is not a gradient): callers must check it (autograd.parameter_vjp does)."""
         prep = lambda t: None if t is None else torch.as_tensor(t).to(self.device, self.dtype).contiguous()
         precip, pet, w_runoff, w_perc = prep(precip), prep(pet), prep(w_runoff), prep(w_perc)
+        if precip.dim() != 2 or precip.shape[1] != self.N or pet.shape != precip.shape:
+            raise LgarError("forcing must be [T, %d]; got %s / %s" % (self.N, tuple(precip.shape), tuple(pet.shape)))
+        for nm, w in (("w_runoff", w_runoff), ("w_perc", w_perc)):
+            if w is not None and w.shape != precip.shape:
+                raise LgarError("%s must be [T, N] like the forcing; got %s" % (nm, tuple(w.shape)))
         T = precip.shape[0]
         dirs = {k: prep(direction.get(k)) for k in ("alpha", "n", "ksat")}
         for k, v in dirs.items():
@@ -182,8 +203,17 @@ class LgarEngine:
         _capi.check(rc, "lgar_forward_tangent")
         return grad, ser, st
 
+    def geff_wave_calls(self, reset=True):
+        """Wave-level Geff evaluations since the last reset (measurement: LgarStepOut.counters[0])."""
+        n = int(self.counters[0].item())
+        if reset:
+            self.counters.zero_()
+        return n
+
     def check_status(self):
         """Raise like the reference does (ValueError) if any column hit a physics fault."""
+        if not bool((self.status != 0).any()):
+            return
         bad = int((self.status != 0).sum().item())
         if bad:
             bits = int(torch.bitwise_or(self.status, torch.zeros_like(self.status)).max().item())
@@ -198,7 +228,8 @@ class LgarEngine:
 
     # ------------------------------------------------------------------------------------------
     def fronts(self):
-        """Front tables as host numpy arrays: depth/theta/psi/k/dzdt [FMAX, N], layer, to_bottom, n_fronts."""
+        """Front tables as host numpy arrays: depth/theta/psi/k/dzdt [front_slots, N], layer, to_bottom, n_fronts (rows at and
+        beyond a column's n_fronts are not meaningful)."""
         fl = self.flags.cpu().numpy()
         return dict(depth=self.depth.cpu().numpy(), theta=self.theta.cpu().numpy(), psi=self.psi.cpu().numpy(),
                     k=self.k.cpu().numpy(), dzdt=self.dzdt.cpu().numpy(), layer=(fl & 0x7F).astype("int8"),
@@ -230,7 +261,7 @@ def leaf_batch(op, x, y=None, z=0.0, *, alpha, n, ksat, theta_e, theta_r, nint=1
     dev = torch.device(device)
     _require_gpu(dev)
     lib = _capi.load()
-    ops = {"theta_from_h": 0, "se_from_h": 1, "k_from_se": 2, "h_from_se": 3, "geff": 4, "aet": 5}
+    ops = {"theta_from_h": 0, "se_from_h": 1, "k_from_se": 2, "h_from_se": 3, "geff": 4, "aet": 5, "geff_literal": 6}
     prep = lambda t: None if t is None else torch.as_tensor(t, dtype=torch.float64).to(dev, dtype).contiguous()
     x, y, alpha, n, ksat, theta_e, theta_r = map(prep, (x, y, alpha, n, ksat, theta_e, theta_r))
     out = torch.empty_like(x)

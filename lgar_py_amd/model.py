@@ -48,7 +48,12 @@ class dpLGAR(nn.Module):
         super().__init__()
         self.cfg = cfg
         self.n_columns = int(n_columns if n_columns is not None else cfg.get("n_columns", 1) or 1)
-        self.device = torch.device(cfg.device if str(cfg.device) != "cpu" else "cuda:0")
+        if str(cfg.device) == "cpu":
+            # the reference only ever runs with `device: cpu` (its configs say so); this engine has no CPU path, and
+            # silently moving the model to a GPU would hide that: ask for the device explicitly
+            raise LgarError("cfg.device is 'cpu': the MI355X LGAR engine has no CPU fallback; set cfg.device to 'cuda:0' "
+                            "(config.load_config does this by default)")
+        self.device = torch.device(cfg.device)
         self.dtype = torch.float32 if str(cfg.get("dtype", "float64")) in ("float32", "f32") else torch.float64
         N = self.n_columns
         alpha_, n_, ksat_ = D.read_test_params(cfg)
@@ -165,18 +170,19 @@ class dpLGAR(nn.Module):
             x = x[None]
         if x.shape[1] != N or x.shape[2] != 2:
             raise LgarError("forcing must be [2], [N, 2] or [T, N, 2] with N = %d" % N)
-        out = self.engine.forward(x[:, :, 0], x[:, :, 1], series=ACC_NAMES[:8], check=False)
         grad_mode = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
-        for nm in ACC_NAMES[:8]:
-            step_sum = out[nm].to(torch.float64).sum(0)
+        want = ("runoff", "percolation") if (series_mode or grad_mode) else ()
+        out = self.engine.forward(x[:, :, 0], x[:, :, 1], series=want, check=False, call_sums=True)
+        sums = out["call_sums"].to(torch.float64)  # the 8 accumulators summed over this call's steps, [8+2, N]
+        for j, nm in enumerate(ACC_NAMES[:8]):
             if grad_mode and nm in ("runoff", "percolation"):
                 continue
-            setattr(self, nm, getattr(self, nm) + self._shape(step_sum))
-        r_series, p_series = out["runoff"], out["percolation"]
+            setattr(self, nm, getattr(self, nm) + self._shape(sums[j]))
+        r_series, p_series = out.get("runoff"), out.get("percolation")
         if grad_mode:
-            # autograd-connected outputs: this block's per-step runoff / percolation are recorded on the step tape; the
-            # parameter gradients are produced by tangent launches when the backward pass ends (autograd.StepTape)
-            r_series, p_series = self.tape.record(x, out["runoff"].to(torch.float64), out["percolation"].to(torch.float64))
+            # graph-connected outputs (models/dpLGAR.py:299): this block's per-step runoff / percolation become the
+            # outputs of an autograd node whose inputs are the parameters (autograd.StepTape)
+            r_series, p_series = self.tape.record(x, r_series.to(torch.float64), p_series.to(torch.float64))
             self.runoff = self.runoff + self._shape(r_series.sum(0))
             self.percolation = self.percolation + self._shape(p_series.sum(0))
         self.previous_precip = self._shape(self.engine.previous_precip.to(torch.float64))

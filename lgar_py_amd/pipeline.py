@@ -10,7 +10,8 @@ import torch
 from .distributed import all_reduce_sum
 
 
-def run_streamed(engine, x, scale=None, pet_scale=None, chunk=512, series=("runoff",), reduce_basin=True, weights=None):
+def run_streamed(engine, x, scale=None, pet_scale=None, chunk=512, series=("runoff",), reduce_basin=True, weights=None,
+                 check=True):
     """Integrate engine over the whole series x[T, 2] (cm/h; precip, PET).
 
     scale / pet_scale: optional [N] per-column forcing multipliers; weights: optional [N] basin weights (area fractions).  Returns {name: [T] basin sums (fp64, all-reduced across
@@ -58,5 +59,6 @@ def run_streamed(engine, x, scale=None, pet_scale=None, chunk=512, series=("runo
         freed[b].record(main)
         for nm in series:
             outs[nm].append(all_reduce_sum(out["basin:" + nm]) if reduce_basin else out[nm])
-    engine.check_status()
+    if check:
+        engine.check_status()  # raises like the reference does when a column left its domain of validity
     return {nm: (torch.cat(v) if v else torch.zeros(0, dtype=torch.float64, device=dev)) for nm, v in outs.items()}

@@ -22,21 +22,15 @@ def golden_dir():
     return GOLDEN
 
 
-_exit_status = {"code": None}
+TESTS = os.path.dirname(os.path.abspath(__file__))
+if TESTS not in sys.path:
+    sys.path.insert(0, TESTS)
 
 
-def pytest_sessionfinish(session, exitstatus):
-    _exit_status["code"] = int(exitstatus)
-
-
-def pytest_unconfigure(config):
-    """After a GPU session leave through os._exit: the tests are over and reported; what remains is interpreter
-    shutdown with live HIP/autograd worker threads, where an exit-time race in the runtime (seen once in ~7 runs of a
-    script that ran a backward pass: "terminate called without an active exception") would turn a green run into
-    exit code 134.  CPU-only sessions exit normally."""
-    import sys
-    torch = sys.modules.get("torch")
-    if torch is not None and _exit_status["code"] is not None and torch.cuda.is_available() and torch.cuda.is_initialized():
-        sys.stdout.flush()
-        sys.stderr.flush()
-        os._exit(_exit_status["code"])
+@pytest.fixture(scope="session", autouse=True)
+def _devsim_libraries(request):
+    """Build the device-code simulator (tests/devsim) for the layer counts the CPU tests use, concurrently, once."""
+    if any("devsim" in str(item.fspath) for item in request.session.items):
+        import devsim
+        devsim.prebuild((2, 3, 4))
+    yield

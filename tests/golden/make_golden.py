@@ -27,7 +27,7 @@ import numpy as np
 import torch
 import yaml
 
-FREC = 16  # front slots recorded per step
+FREC = 16  # front slots recorded per step (40 for the many-front cases)
 
 # P-1..3 soils (data/utils.py:123-125,146-148,170-172 and data/vG_default_params.dat:14-16)
 PHIL = dict(
@@ -134,7 +134,7 @@ def _f(t):
     return float(t.detach()) if torch.is_tensor(t) else float(t)
 
 
-def fronts_table(model):
+def fronts_table(model, FREC=FREC):
     z = np.zeros((FREC, 5))
     lay = np.full((FREC,), -1, dtype=np.int8)
     bot = np.zeros((FREC,), dtype=np.int8)
@@ -155,8 +155,20 @@ ACC_NAMES = ["precip", "PET", "AET", "infiltration", "runoff", "percolation", "g
              "ponded_water", "ending_volume"]
 
 
+def pulse_forcing(T, a0, decay, gap):
+    """Rain pulses of one step, each `decay` times the previous, `gap` dry steps apart (cm/h): every pulse starts a new
+    surficial front that is slower than the ones below it, so the front lists grow by one per pulse."""
+    pr = np.zeros(T)
+    a = a0
+    for t in range(0, T, gap + 1):
+        pr[t] = a
+        a *= decay
+    return np.stack([pr, np.zeros(T)], axis=1)
+
+
 def run_case(name, forcing, soil, pdm, subcycle_s, forcing_res_s, endtime_h, forcing_scale=1.0, grad=False,
-             record_fronts=True, initial_psi=2000.0, closed_form=False, frozen_factor=1):
+             record_fronts=True, initial_psi=2000.0, closed_form=False, frozen_factor=1, pulse=None, frec=FREC):
+    FREC = frec
     torch.set_default_dtype(torch.float64)
     torch.manual_seed(0)
     from dpLGAR.data.Data import Data
@@ -169,6 +181,8 @@ def run_case(name, forcing, soil, pdm, subcycle_s, forcing_res_s, endtime_h, for
     data = Data(cfg)
     x = data.x * forcing_scale
     T = x.shape[0]
+    if pulse is not None:  # programmatic forcing (cm/h) in place of the file's values; the file only sets T
+        x = torch.tensor(pulse_forcing(T, **pulse))
     model = make_model(cfg, soil)
     mb = MassBalance(cfg, model)
 
@@ -179,7 +193,7 @@ def run_case(name, forcing, soil, pdm, subcycle_s, forcing_res_s, endtime_h, for
     fr = np.zeros((T, FREC, 5)) if record_fronts else None
     fl = np.full((T, FREC), -1, dtype=np.int8) if record_fronts else None
     fb = np.zeros((T, FREC), dtype=np.int8) if record_fronts else None
-    z0, l0, b0, n0 = fronts_table(model)
+    z0, l0, b0, n0 = fronts_table(model, FREC)
     init_volume = _f(model.ending_volume)
     crash_step = -1
     crash_msg = ""
@@ -200,7 +214,7 @@ def run_case(name, forcing, soil, pdm, subcycle_s, forcing_res_s, endtime_h, for
                 acc[i, j] = _f(getattr(model, nm))
             prevp[i] = _f(model.previous_precip)
             gq[i] = model.giuh_runoff_queue.detach().numpy()
-            z, lay, bot, k = fronts_table(model)
+            z, lay, bot, k = fronts_table(model, FREC)
             nfr[i] = k
             if record_fronts:
                 fr[i], fl[i], fb[i] = z, lay, bot
@@ -220,7 +234,7 @@ def run_case(name, forcing, soil, pdm, subcycle_s, forcing_res_s, endtime_h, for
     if record_fronts:
         out.update(fronts=fr, front_layer=fl, front_bottom=fb)
     else:
-        z, lay, bot, k = fronts_table(model)
+        z, lay, bot, k = fronts_table(model, FREC)
         out.update(final_fronts=z, final_layer=lay, final_bottom=bot)
     if grad and crash_step < 0:
         y = torch.stack(runoffs)
@@ -382,6 +396,35 @@ for s in range(8):
 for s in range(4):
     CASES["phil_pert%d_500" % s] = (run_case, dict(
         forcing=PH, soil=perturbed(PHIL, 100 + s), pdm=2, subcycle_s=3600, forcing_res_s=3600, endtime_h=500.0))
+
+
+# many fronts per column (the reference's lists are unbounded, Layer.py:1336-1416): decaying rain pulses, front counts
+# reach ~25; exercises the kernels' front-capacity chain (8 -> 16 -> 32 slots) against the reference itself
+_PULSE = dict(a0=1.2, decay=0.95, gap=1)
+CASES["manyfronts_pulse_84"] = (run_case, dict(forcing=PH, soil=PHIL, pdm=0.0, subcycle_s=3600, forcing_res_s=3600, endtime_h=84.0,
+                                                pulse=_PULSE, frec=40))
+CASES["grad_manyfronts_60"] = (run_case, dict(forcing=PH, soil=PHIL, pdm=0.0, subcycle_s=3600, forcing_res_s=3600, endtime_h=60.0,
+                                              pulse=_PULSE, frec=40, grad=True))
+# gradient fixtures on ensemble members (BASELINE configs[4]): +-10 % perturbed soils with scaled forcing, and one draw
+# from the wide parameter ranges of models/config/shorter_subcycle.yaml:23-32
+for s in (2, 6):
+    rng = np.random.default_rng(1000 + s)
+    CASES["grad_synth1_pert%d" % s] = (run_case, dict(
+        forcing="forcing_data_synth_1.txt", soil=perturbed(PHIL, s), pdm=0.0, subcycle_s=300, forcing_res_s=300,
+        endtime_h=12.0, forcing_scale=float(0.5 + rng.random()), grad=True))
+
+
+def wide_member(seed):
+    rng = np.random.default_rng(seed)
+    return dict(alpha=[float(v) for v in 0.0015 + (0.015 - 0.0015) * rng.random(3)],
+                n=[float(v) for v in 1.1 + (3.0 - 1.1) * rng.random(3)],
+                ksat=[float(v) for v in 0.01 + (5.0 - 0.01) * rng.random(3)],
+                theta_e=list(PHIL["theta_e"]), theta_r=list(PHIL["theta_r"]), thickness=list(PHIL["thickness"]))
+
+
+for s in (5, 9):
+    CASES["grad_wide%d" % s] = (run_case, dict(forcing="forcing_data_synth_1.txt", soil=wide_member(500 + s), pdm=0.0,
+                                               subcycle_s=300, forcing_res_s=300, endtime_h=12.0, grad=True))
 
 
 def _run(name):

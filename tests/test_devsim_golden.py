@@ -1,0 +1,198 @@
+"""CPU: the DEVICE CODE (lgar_py_amd/csrc/*.hpp: column physics, per-lane kernel bodies, front-capacity chain, tangent
+kernels) compiled for the host by the test-only simulator (tests/devsim) against the vectors captured from the reference.
+The same source runs on the GPU (tests/test_gpu_*.py repeat these checks there through the C-ABI); here logic errors
+surface without a GPU.  Tolerances as on the GPU: fp64 1e-6 relative per step (observed <= 5e-8)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, golden_names
+
+
+def _rel(a, b, floor=1e-6):
+    return np.abs(a - b) / np.maximum(np.abs(b), floor)
+
+
+def _engine(g, ncol, dtype=np.float64, **kw):
+    import devsim
+    return devsim.SimEngine(g["alpha"], g["n"], g["ksat"], g["theta_e"], g["theta_r"], g["thickness"], n_columns=ncol,
+                            dt_h=float(g["dt_h"]), num_subcycles=int(g["num_subcycles"]), ponded_depth_max=float(g["pdm"]),
+                            initial_psi=float(g["initial_psi"]), wilting_point_psi=float(g["wilting_point_psi"]),
+                            frozen_factor=float(g["frozen_factor"]), nint=int(g["nint"]),
+                            giuh_ordinates=tuple(g["giuh_ordinates"]), dtype=dtype,
+                            use_closed_form_G=bool(g["closed_form"]) if "closed_form" in g.files else False, **kw)
+
+
+TRAJ = [n for n in golden_names() if not n.startswith("grad_")]
+
+
+@pytest.mark.parametrize("mode", [1, 2], ids=["fast", "fast_capacity_chain"])
+@pytest.mark.parametrize("name", TRAJ)
+def test_device_code_fp64_trajectory_vs_reference_golden(name, mode):
+    import devsim
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    crash = int(g["crash_step"])
+    T = crash if crash >= 0 else g["forcing"].shape[0]
+    eng = _engine(g, 2, search_mode=mode)
+    assert abs(float(eng.scalars[2, 0]) - float(g["init_volume"])) <= 1e-9
+    f = g["forcing"][:T]
+    out = eng.forward(np.repeat(f[:, 0:1], 2, 1), np.repeat(f[:, 1:2], 2, 1), series=devsim.ACC_NAMES, call_sums=True)
+    for j, nm in enumerate(devsim.ACC_NAMES):
+        assert _rel(out[nm][:, 0], g["acc"][:T, j]).max() <= 1e-6, nm
+        assert (out[nm][:, 0] == out[nm][:, 1]).all()
+    assert (eng.status == 0).all()
+    nf = int(g["nfronts"][T - 1])
+    fr = eng.fronts()
+    assert (fr["n_fronts"] == nf).all()
+    assert _rel(fr["depth"][:nf, 0], g["fronts"][T - 1, :nf, 0]).max() <= 1e-6
+    assert _rel(fr["theta"][:nf, 0], g["fronts"][T - 1, :nf, 1]).max() <= 1e-6
+    assert _rel(fr["psi"][:nf, 0], g["fronts"][T - 1, :nf, 2], 1e-3).max() <= 1e-5
+    assert _rel(fr["k"][:nf, 0], g["fronts"][T - 1, :nf, 3], 1e-12).max() <= 1e-5
+    assert _rel(fr["dzdt"][:nf, 0], g["fronts"][T - 1, :nf, 4], 1e-9).max() <= 1e-5
+    assert (fr["layer"][:nf, 0] == g["front_layer"][T - 1, :nf]).all()
+    assert (fr["to_bottom"][:nf, 0] == g["front_bottom"][T - 1, :nf]).all()
+    for j in range(8):  # run totals (MassBalance) and the per-call sums the model surface reads
+        assert _rel(float(eng.totals[j, 0]), g["acc"][:T, j].sum()) <= 1e-6
+        assert _rel(float(out["call_sums"][j, 0]), g["acc"][:T, j].sum()) <= 1e-6
+    if crash >= 0:  # the reference raised at this step: the column must fault here too
+        f1 = g["forcing"][T:T + 1]
+        eng.forward(np.repeat(f1[:, 0:1], 2, 1), np.repeat(f1[:, 1:2], 2, 1), series=())
+        assert (eng.status != 0).all()
+
+
+@pytest.mark.parametrize("name", ["synth1_phil", "phil_hourly_3000", "four_layer_synth0_600", "two_layer_phil_600",
+                                  "closedG_synth1_phil", "frozen07_phil_hourly_400", "manyfronts_pulse_84", "rand06"])
+def test_device_code_literal_mode_vs_reference_golden(name):
+    """search_mode 0: the reference's literal line searches, update_psi pass and (fp64) operation-by-operation trapezoid."""
+    import devsim
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    crash = int(g["crash_step"])
+    T = crash if crash >= 0 else g["forcing"].shape[0]
+    eng = _engine(g, 1, search_mode=0)
+    f = g["forcing"][:T]
+    out = eng.forward(f[:, 0:1], f[:, 1:2], series=devsim.ACC_NAMES)
+    for j, nm in enumerate(devsim.ACC_NAMES):
+        assert _rel(out[nm][:, 0], g["acc"][:T, j]).max() <= 1e-7, nm  # observed <= 2e-9
+    assert int(eng.n_fronts[0]) == int(g["nfronts"][T - 1]) and int(eng.status[0]) == 0
+
+
+def test_capacity_chain_hands_columns_over_and_resumes():
+    """Columns with few fronts finish in the 8-slot kernel, the others move to 16 and 32 slots at different steps of the
+    same call; results equal the single-kernel run bitwise, chunked calls included, and the per-call sums add up."""
+    import devsim
+    g = np.load(os.path.join(GOLDEN, "manyfronts_pulse_84.npz"))
+    N, T = 6, 84
+    scale = np.array([1.0, 0.0, 1.0, 0.3, 1.0, 0.6])  # column 1 never sees rain, the others grow at different rates
+    pr = g["forcing"][:T, 0:1] * scale[None, :]
+    pe = np.zeros_like(pr)
+    a = _engine(g, N, search_mode=1)
+    ref = a.forward(pr, pe, series=devsim.ACC_NAMES, basin=("runoff", "infiltration"), call_sums=True)
+    assert a.n_fronts.max() > 16 and a.n_fronts.min() == 3 and (a.status == 0).all()
+    b = _engine(g, N, search_mode=2)
+    got = b.forward(pr, pe, series=devsim.ACC_NAMES, basin=("runoff", "infiltration"), call_sums=True)
+    for nm in ref:
+        if nm.startswith("basin") or nm == "call_sums":  # sums are split at the hand-over points: last-bit differences
+            assert np.allclose(got[nm], ref[nm], rtol=1e-13, atol=1e-15), nm
+        else:
+            assert np.array_equal(got[nm], ref[nm]), nm
+    for x, y in ((a.depth, b.depth), (a.theta, b.theta), (a.psi, b.psi), (a.dzdt, b.dzdt), (a.flags, b.flags),
+                 (a.n_fronts, b.n_fronts), (a.scalars, b.scalars), (a.status, b.status)):
+        assert np.array_equal(x, y)
+    assert np.allclose(a.totals, b.totals, rtol=1e-14, atol=0)
+    c = _engine(g, N, search_mode=2)  # ragged chunks: hand-overs happen in different calls
+    parts = []
+    for lo, hi in ((0, 7), (7, 30), (30, 31), (31, 70), (70, 84)):
+        parts.append(c.forward(pr[lo:hi], pe[lo:hi], series=("runoff", "ending_volume"), call_sums=True))
+        assert (c.status == 0).all()  # LGAR_ST_RESUME never survives a call
+    assert np.array_equal(np.concatenate([p["runoff"] for p in parts]), ref["runoff"])
+    assert np.array_equal(np.concatenate([p["ending_volume"] for p in parts]), ref["ending_volume"])
+    assert np.allclose(sum(p["call_sums"][:8] for p in parts), ref["call_sums"][:8], rtol=1e-13, atol=1e-15)
+    assert np.array_equal(c.n_fronts, a.n_fronts) and np.array_equal(c.depth, a.depth)
+
+
+def test_front_overflow_is_flagged_at_the_reference_state_limit():
+    """The reference's lists are unbounded; here a column holds at most front_slots (<= 32) fronts: one more -> the
+    column stops with LGAR_ST_OVERFLOW, in every mode, with the state arrays never written past their rows."""
+    import devsim
+    g = np.load(os.path.join(GOLDEN, "manyfronts_pulse_84.npz"))
+    f = np.concatenate([g["forcing"], g["forcing"][:40] * 0 + np.array([[0.02, 0.0]])])  # keep pulsing past 32 fronts
+    T = g["forcing"].shape[0]
+    for mode in (0, 1, 2):
+        for slots in (None, 10):
+            eng = _engine(g, 1, search_mode=mode, front_slots=slots)
+            pr = np.concatenate([g["forcing"][:, 0], np.tile([0.02, 0.0], 30)])[:, None]
+            eng.forward(pr, np.zeros_like(pr), series=())
+            lim = slots or 32
+            assert int(eng.status[0]) & 8, (mode, slots)
+            assert int(eng.n_fronts[0]) == lim
+            assert eng.depth.shape[0] == lim
+
+
+def test_device_code_fp32_close_to_reference():
+    """The fp32 instantiation (bench.py's configuration; host libm stands in for v_log_f32 / v_exp_f32) on the golden
+    cases of its workload family: run totals within 5e-3 of the reference."""
+    import devsim
+    for name in ("synth1_phil", "synth1_pert0", "synth1_pert3", "synth2_phil", "phil_pert1_500"):
+        g = np.load(os.path.join(GOLDEN, name + ".npz"))
+        eng = _engine(g, 1, dtype=np.float32)
+        f = g["forcing"]
+        eng.forward(f[:, 0:1], f[:, 1:2], series=())
+        assert int(eng.status[0]) == 0
+        ref = g["acc"][:, :8].sum(0)
+        got = eng.totals[:8, 0].astype(np.float64)
+        scale = max(ref[0], 1.0)  # precipitation scale
+        assert np.abs(got - ref).max() <= 5e-3 * scale, (name, got, ref)
+        assert abs(float(eng.totals[9, 0]) - g["acc"][-1, 9]) <= 5e-3 * g["acc"][-1, 9]
+
+
+GRADS = [n for n in golden_names() if n.startswith("grad_")]
+
+
+@pytest.mark.parametrize("mode", [1, 2, 0], ids=["fast", "fast_capacity_chain", "literal"])
+@pytest.mark.parametrize("name", GRADS)
+def test_device_tangent_matches_reference_autograd(name, mode):
+    """Forward-mode tangents of the device code (Dual numbers) contracted with d loss / d runoff_t reproduce the gradients
+    torch autograd produced through the reference (loss = mean(runoff^2)): nominal, 4-layer, +-10 % ensemble members,
+    wide-range ensemble members, and a column with up to 19 fronts."""
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    f = g["forcing"]
+    T = f.shape[0]
+    L = len(g["alpha"])
+    eng = _engine(g, 1, search_mode=mode)
+    out = eng.forward(f[:, 0:1], f[:, 1:2], series=("runoff",))
+    r = out["runoff"][:, 0]
+    loss = float(np.mean(r * r))
+    assert abs(loss - float(g["loss"])) <= 1e-9 * float(g["loss"])
+    w = (2.0 * r / T)[:, None]
+    for kind, ref in (("alpha", g["d_alpha"]), ("n", g["d_n"]), ("ksat", g["d_ksat"])):
+        ref = np.nan_to_num(ref, nan=0.0)  # None in the reference = no dependence
+        got = np.zeros(L)
+        for l in range(L):
+            d = np.zeros((L, 1))
+            d[l] = 1.0
+            gr, _, st = eng.tangent({kind: d}, f[:, 0:1], f[:, 1:2], w_runoff=w)
+            assert int(st[0]) == 0
+            got[l] = gr[0]
+        assert np.abs(got - ref).max() <= 1e-6 * np.abs(ref).max(), (kind, got, ref)
+
+
+def test_tangent_capacity_chain_and_status():
+    """Tangent kernels: the 8-slot kernel hands the many-front column to the 32-slot kernel (same gradient as the
+    single-kernel run), and a column that overflows even that reports it in the tangent status."""
+    g = np.load(os.path.join(GOLDEN, "grad_manyfronts_60.npz"))
+    f = g["forcing"]
+    T = f.shape[0]
+    N = 3
+    scale = np.array([1.0, 0.0, 0.5])
+    pr, pe = f[:, 0:1] * scale[None, :], np.zeros((T, N))
+    w = np.ones((T, N))
+    d = np.zeros((3, N))
+    d[0] = 1.0
+    g1, _, s1 = _engine(g, N, search_mode=1).tangent({"ksat": d}, pr, pe, w_runoff=w)
+    g2, _, s2 = _engine(g, N, search_mode=2).tangent({"ksat": d}, pr, pe, w_runoff=w)
+    assert (s1 == 0).all() and (s2 == 0).all()
+    assert np.array_equal(g1, g2) and g1[0] != 0.0 and g1[1] == 0.0
+    long = np.concatenate([np.load(os.path.join(GOLDEN, "manyfronts_pulse_84.npz"))["forcing"][:, 0], np.tile([0.02, 0.0], 30)])[:, None]
+    gl, _, sl = _engine(g, 1, search_mode=2).tangent({"ksat": d[:, :1]}, long, np.zeros_like(long), w_runoff=np.ones_like(long))
+    assert int(sl[0]) & 8

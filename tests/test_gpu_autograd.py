@@ -25,9 +25,17 @@ def _setup(g, N, dtype=torch.float64, **kw):
     return P, pr, pe, ekw
 
 
-@pytest.mark.parametrize("name", ["grad_synth0_12h", "grad_synth1_phil", "grad_synth0_60h", "grad_four_layer_synth1"])
-@pytest.mark.parametrize("mode", [1, 0], ids=["fast_search", "literal_search"])
+from conftest import golden_names
+
+GRADS = [n for n in golden_names() if n.startswith("grad_")]
+
+
+@pytest.mark.parametrize("name", GRADS)
+@pytest.mark.parametrize("mode", [1, 2, 0], ids=["fast_search", "fast_capacity_chain", "literal_search"])
 def test_gradients_match_reference_autograd(name, mode):
+    """Fixtures from the reference's own loss.backward(): nominal Phillipsburg, 4 layers, +-10 % ensemble members
+    (grad_synth1_pert*), wide-range ensemble members (grad_wide*: BASELINE configs[4]'s parameter ranges) and a column
+    with up to 19 fronts (grad_manyfronts_60: more than the 8-slot tangent kernel holds -> capacity chain)."""
     from lgar_py_amd.autograd import lgar_series
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     N = 3
@@ -36,15 +44,19 @@ def test_gradients_match_reference_autograd(name, mode):
         P[k].requires_grad_(True)
     runoff, perc = lgar_series(P["alpha"], P["n"], P["ksat"], P["theta_e"], P["theta_r"], P["thickness"], pr, pe, **ekw)
     assert runoff.requires_grad
+    assert runoff.grad_fn is not None
     loss = torch.mean(runoff[:, 0] ** 2)
     assert abs(float(loss) - float(g["loss"])) <= 1e-9 * float(g["loss"])
+    # torch.autograd.grad works like for the reference's graph (models/dpLGAR.py:299), and so does backward()
+    ga, gn, gk = torch.autograd.grad(loss, [P["alpha"], P["n"], P["ksat"]], retain_graph=True)
     loss.backward()
-    for k, ref in (("alpha", g["d_alpha"]), ("n", g["d_n"]), ("ksat", g["d_ksat"])):
+    for k, ref, direct in (("alpha", g["d_alpha"], ga), ("n", g["d_n"], gn), ("ksat", g["d_ksat"], gk)):
         got = P[k].grad[:, 0].cpu().numpy()
         ref = np.nan_to_num(ref, nan=0.0)  # None in the reference = no dependence
         scale = np.abs(ref).max()
         assert np.abs(got - ref).max() <= 1e-6 * scale, (k, got, ref)
         assert np.abs(P[k].grad[:, 1:].cpu().numpy()).max() == 0.0  # other columns do not enter the loss
+        assert torch.equal(direct, P[k].grad)
 
 
 def test_tangent_matches_finite_differences():
@@ -117,14 +129,31 @@ def test_stepwise_model_backward_equals_series_backward(tmp_path):
         ys.append(runoff)
         mb.change_mass(model)
     y = torch.stack(ys)
-    assert y.requires_grad
+    assert y.requires_grad and y.grad_fn is not None  # graph-connected like the reference's outputs (models/dpLGAR.py:299)
     loss = torch.mean(y * y)
     assert abs(float(loss) - float(g["loss"])) <= 1e-9 * float(g["loss"])
+    direct = torch.autograd.grad(loss, list(model.parameters()), retain_graph=True, allow_unused=True)
     loss.backward()
     for plist, ref in ((model.alpha, g["d_alpha"]), (model.n, g["d_n"]), (model.ksat, g["d_ksat"])):
         ref = np.nan_to_num(ref, nan=0.0)
         got = np.array([float(p.grad) for p in plist])
         assert np.abs(got - ref).max() <= 1e-6 * np.abs(ref).max(), (got, ref)
+    for p, d in zip(model.parameters(), direct):
+        assert d is not None and float(d) == float(p.grad)
+    # a loss on part of the series only (steps 6..11) still reaches the parameters through the chained nodes
+    for p in model.parameters():
+        p.grad = None
+    torch.mean(y[6:] * y[6:]).backward()
+    assert float(model.ksat[0].grad) != 0.0
+    # changing the parameters in the middle of a recorded series is refused (the gradient would belong to another run)
+    with torch.no_grad():
+        model.alpha[0].mul_(1.0001)
+    with pytest.raises(RuntimeError, match="parameters changed"):
+        model(x[0])
+    model.set_internal_states()
+    model(x[0])
+    for p in model.parameters():
+        p.grad = None
     before = float(model.alpha[0])
     opt.step()
     assert float(model.alpha[0]) != before
@@ -154,11 +183,47 @@ def test_ensemble_gradients_config5_shape():
     assert 0.3 < float(ok.double().mean()) < 1.0
     loss = torch.mean(runoff[:, ok] ** 2)  # faulted columns are masked out of the loss
     loss.backward()
+    assert len(st) == 2  # the backward pass appended the tangent status: columns whose gradient integration faulted
+    tok = st[1] == 0
+    assert float(tok.double().mean()) > 0.9
     for k in ("alpha", "n", "ksat"):
         gk = P[k].grad
-        assert gk.shape == (3, N) and bool(torch.isfinite(gk[:, ok]).all())
-        assert float(gk[:, ~ok].abs().sum()) == 0.0
+        assert gk.shape == (3, N) and bool(torch.isfinite(gk).all())
+        assert float(gk[:, ~ok].abs().sum()) == 0.0 and float(gk[:, ~tok].abs().sum()) == 0.0
     assert float(P["ksat"].grad[0].abs().sum()) > 0
+    # per-column gradients equal the single-column gradients of the same member (columns are independent): spot-check
+    # three members against the reference-pinned single-column path
+    from lgar_py_amd.autograd import lgar_series as series
+    for c in [int(i) for i in torch.nonzero(ok & tok).flatten()[:3]]:
+        Q = {k: P[k].detach()[:, c:c + 1].clone() for k in P}
+        for k in ("alpha", "n", "ksat"):
+            Q[k].requires_grad_(True)
+        r1, _ = series(Q["alpha"], Q["n"], Q["ksat"], Q["theta_e"], Q["theta_r"], Q["thickness"], pr[:, c:c + 1].contiguous(),
+                       pe[:, c:c + 1].contiguous(), dt_h=300.0 / 3600.0, ponded_depth_max=0.0, dtype=torch.float64)
+        (torch.sum(r1 ** 2) / (T * int(ok.sum()))).backward()
+        for k in ("alpha", "n", "ksat"):
+            assert torch.allclose(Q[k].grad[:, 0], P[k].grad[:, c], rtol=1e-9, atol=1e-18), (c, k)
+
+
+def test_tangent_faults_are_reported_not_swallowed():
+    """A column whose tangent integration faults (here: more than 32 fronts) has no gradient: parameter_vjp raises
+    (check=True) or zeroes that column's entries and reports the status (check=False); clean columns are unaffected."""
+    import lgar_py_amd as lg
+    from lgar_py_amd.autograd import parameter_vjp
+    g = np.load(os.path.join(GOLDEN, "manyfronts_pulse_84.npz"))
+    P, _, _, ekw = _setup(g, 2)
+    pulses = np.concatenate([g["forcing"][:, 0], np.tile([0.02, 0.0], 30)])
+    pr = torch.tensor(np.stack([pulses, np.where(np.arange(len(pulses)) < 40, pulses, 0.0)], axis=1), device="cuda")
+    pe = torch.zeros_like(pr)
+    eng = lg.LgarEngine(P["alpha"], P["n"], P["ksat"], P["theta_e"], P["theta_r"], P["thickness"], **ekw)
+    w = torch.ones_like(pr)
+    with pytest.raises(lg.LgarStatusError, match="tangent"):
+        parameter_vjp(eng, pr, pe, w, None, [("ksat", 0), ("n", 0)])
+    vj, st = parameter_vjp(eng, pr, pe, w, None, [("ksat", 0), ("n", 0)], check=False)
+    assert int(st[0]) & 8 and int(st[1]) == 0
+    assert float(vj[("ksat", 0)][0]) == 0.0 and float(vj[("ksat", 0)][1]) != 0.0
+    with pytest.raises(lg.LgarError, match=r"\[T, N\]"):
+        eng.tangent({"ksat": torch.ones(3, 2)}, pr, pe, w_runoff=w[:5])
 
 
 def test_agent_twin_experiment_reduces_loss(tmp_path):

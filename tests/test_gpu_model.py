@@ -92,6 +92,43 @@ def test_batched_forward_and_ensemble(tmp_path):
     assert abs(float(model.engine.ksat[0, 0]) - 0.225) < 1e-12
 
 
+def test_streamed_run_matches_reference_golden():
+    """the streamed driver (pinned host -> side-stream expansion -> chunked launches, basin sums from the
+    kernel epilogue) on the bundled 3000-hour Phillipsburg forcing against the accumulators the reference produced, step
+    by step; and against the oracle on heterogeneous columns."""
+    import lgar_py_amd as lg
+    from lgar_py_amd import workloads as W
+    from lgar_py_amd.pipeline import run_streamed
+    from oracle import lgar_oracle as O
+    g = np.load(os.path.join(GOLDEN, "phil_hourly_3000.npz"))
+    x = g["forcing"]
+    T, N = x.shape[0], 192
+    kw = dict(dt_h=1.0, ponded_depth_max=2.0, dtype=torch.float64)
+    eng = lg.LgarEngine(g["alpha"], g["n"], g["ksat"], g["theta_e"], g["theta_r"], g["thickness"], n_columns=N, **kw)
+    names = ("runoff", "AET", "infiltration", "ending_volume", "giuh_runoff")
+    basin = run_streamed(eng, x, chunk=411, series=names)
+    for nm in names:
+        ref = g["acc"][:, lg.ACC_NAMES.index(nm)]
+        got = basin[nm].cpu().numpy() / N
+        assert np.abs(got - ref).max() <= 1e-6 * max(np.abs(ref).max(), 1e-6), nm
+    for j in range(8):
+        assert abs(float(eng.totals[j, 0]) - g["acc"][:, j].sum()) <= 1e-6 * max(abs(g["acc"][:, j].sum()), 1e-6)
+    # heterogeneous columns + per-column forcing scale + area weights: basin series == oracle's weighted column sum
+    N2, T2 = 128, 600
+    P = W.perturbed_columns(N2, seed=51)
+    sc = W.forcing_scale(N2, 0.5, 1.5, seed=52)
+    w = np.random.default_rng(53).random(N2)
+    pr = x[:T2, 0:1] * sc[None, :]
+    pe = x[:T2, 1:2] * np.ones((1, N2))
+    ro, pc, acc, st = O.run_columns(P["alpha"], P["n"], P["ksat"], P["theta_e"], P["theta_r"], P["thickness"], pr, pe, pdm=2.0, dt_h=1.0)
+    e2 = lg.LgarEngine(P["alpha"], P["n"], P["ksat"], P["theta_e"], P["theta_r"], P["thickness"], **kw)
+    ok = st == 0  # columns the reference would raise on carry weight 0
+    got = run_streamed(e2, x[:T2], scale=sc, chunk=128, series=("runoff",), weights=w * ok, check=False)["runoff"].cpu().numpy()
+    assert ((e2.status.cpu().numpy() != 0) == (st != 0)).all()
+    want = (ro * (w * ok)[None, :]).sum(1)
+    assert np.abs(got - want).max() <= 1e-6 * max(want.max(), 1e-6)
+
+
 def test_streamed_run_equals_single_shot():
     """pipeline.run_streamed (double-buffered chunks on a side stream) == one launch over the whole [T, N] forcing."""
     import lgar_py_amd as lg
@@ -123,6 +160,7 @@ def test_in_kernel_basin_aggregation():
     column sums of the per-step series, with and without weights, including a ragged tail wave."""
     import lgar_py_amd as lg
     from lgar_py_amd import workloads as W
+    from oracle import lgar_oracle as O
     for N in (70, 1000):
         P = W.perturbed_columns(N, seed=41)
         sc = W.forcing_scale(N, 0.5, 1.0, seed=42)
@@ -130,6 +168,15 @@ def test_in_kernel_basin_aggregation():
         pr = torch.tensor(f[:, 0:1] * sc[None, :])
         pe = torch.zeros_like(pr)
         w = torch.rand(N, dtype=torch.float64)
+        # the checker: the oracle's per-column runoff, summed over columns (weighted / unweighted), valid columns only
+        ro, _, _, ost = O.run_columns(P["alpha"], P["n"], P["ksat"], P["theta_e"], P["theta_r"], P["thickness"], pr.numpy(),
+                                      pe.numpy(), pdm=0.0, dt_h=300.0 / 3600.0)
+        okw = torch.tensor((ost == 0).astype(np.float64))
+        e0 = lg.LgarEngine(P["alpha"], P["n"], P["ksat"], P["theta_e"], P["theta_r"], P["thickness"], dt_h=300.0 / 3600.0,
+                           ponded_depth_max=0.0, dtype=torch.float64)
+        b0 = e0.forward(pr, pe, series=(), basin=("runoff",), weights=w * okw, check=False)["basin:runoff"].cpu().numpy()
+        want = (ro * (w * okw).numpy()[None, :]).sum(1)
+        assert np.abs(b0 - want).max() <= 1e-6 * want.max(), N
         for dtype, tol in ((torch.float64, 1e-13), (torch.float32, 1e-6)):
             eng = lg.LgarEngine(P["alpha"], P["n"], P["ksat"], P["theta_e"], P["theta_r"], P["thickness"],
                                 dt_h=300.0 / 3600.0, ponded_depth_max=0.0, dtype=dtype)

@@ -32,7 +32,7 @@ def probe(op, waves_per_simd, iters=2000, rounds=4, n_cu=256):
         assert rc == 0, rc
         ms = a.elapsed_time(b)
         best = ms if best is None or ms < best else best
-    wave_insts = nwg * iters * 64
+    wave_insts = nwg * iters * lib.lgar_valu_probe_insts(OPS.index(op))
     per_s = wave_insts / (best * 1e-3)
     return dict(op=op, waves_per_simd=waves_per_simd, ms=best, wave_insts_per_s=per_s,
                 lane_ops_per_s=per_s * 64, cycles_per_wave_inst_per_simd_at_2p4GHz=2.4e9 * n_cu * 4 / per_s)
