@@ -55,6 +55,13 @@ __device__ __forceinline__ unsigned long long any_lane(bool p) { return p ? 1ull
 __device__ __forceinline__ bool first_active_lane() { return true; }
 #endif
 __device__ __forceinline__ float pw(float x, float y) { return ex2(y * lg2(x)); }
+// EX = true (verification mode, double precision only): the correctly rounded library pow, as the reference's torch.pow;
+// otherwise the lean pow above
+template <bool EX> __device__ __forceinline__ double pwx(double x, double y) {
+  if constexpr (EX) return pow(x, y);
+  return pw(x, y);
+}
+template <bool EX> __device__ __forceinline__ float pwx(float x, float y) { return pw(x, y); }
 #ifdef LGAR_F64_LIBM
 __device__ __forceinline__ double lg2(double x) { return log2(x); }
 __device__ __forceinline__ double ex2(double x) { return exp2(x); }
@@ -135,10 +142,10 @@ template <typename S, int NL> __device__ __forceinline__ LayerK<S> pick_static(c
 // van Genuchten leaf functions (models/physics/utils.py)
 // ---------------------------------------------------------------------------------------------
 // calc_theta_from_h, utils.py:35-51
-template <typename S> __device__ __forceinline__ S theta_from_h(const LayerK<S> &l, S h) {
+template <typename S, bool EX = false> __device__ __forceinline__ S theta_from_h(const LayerK<S> &l, S h) {
   using R = real_t<S>;
-  S ap = pw(l.alpha * h, l.n);
-  S op = pw(R(1.0) + ap, l.m);
+  S ap = pwx<EX>(l.alpha * h, l.n);
+  S op = pwx<EX>(R(1.0) + ap, l.m);
   return (R(1.0) / op * (l.te - l.tr)) + l.tr;
 }
 // calc_se_from_theta, utils.py:102-112
@@ -146,49 +153,49 @@ template <typename S> __device__ __forceinline__ S se_from_theta(const LayerK<S>
   return (theta - l.tr) / (l.te - l.tr);
 }
 // calc_se_from_h, utils.py:115-131 (exactly 1 for |h| < 0.1)
-template <typename S> __device__ __forceinline__ S se_from_h(const LayerK<S> &l, S h) {
+template <typename S, bool EX = false> __device__ __forceinline__ S se_from_h(const LayerK<S> &l, S h) {
   using R = real_t<S>;
   if (ab(val(h)) < R(1.0e-01)) return S(R(1.0));
-  S is = pw(l.alpha * h, l.n);
-  return R(1.0) / pw(R(1.0) + is, l.m);
+  S is = pwx<EX>(l.alpha * h, l.n);
+  return R(1.0) / pwx<EX>(R(1.0) + is, l.m);
 }
 // calc_k_from_se, utils.py:134-156; torch.isclose(base, 0, rtol=1e-12) => |base| <= 1e-8 (default atol)
-template <typename S> __device__ __forceinline__ S k_from_se(const LayerK<S> &l, S se) {
+template <typename S, bool EX = false> __device__ __forceinline__ S k_from_se(const LayerK<S> &l, S se) {
   using R = real_t<S>;
-  S sp = pw(se, l.inv_m);
+  S sp = pwx<EX>(se, l.inv_m);
   S base = R(1.0) - sp;
   if (ab(val(base)) <= R(1e-8)) base = base + R(1e-12);
-  S op = pw(base, l.m);
+  S op = pwx<EX>(base, l.m);
   S t = R(1.0) - op;
   return l.ksat * sq(se) * (t * t);
 }
 // calc_h_from_se, utils.py:159-174
-template <typename S> __device__ __forceinline__ S h_from_se(const LayerK<S> &l, S se) {
+template <typename S, bool EX = false> __device__ __forceinline__ S h_from_se(const LayerK<S> &l, S se) {
   using R = real_t<S>;
-  S sp = pw(se, l.ninv_m);
+  S sp = pwx<EX>(se, l.ninv_m);
   S base = sp - R(1.0);
   if (ab(val(base)) <= R(1e-8)) base = base + R(1e-12);
-  S op = pw(base, l.inv_n);
+  S op = pwx<EX>(base, l.inv_n);
   return R(1.0) / l.alpha * op;
 }
 // calc_geff, models/physics/lgar/green_ampt.py:45-84: nint-interval trapezoid of K(h) dh / Ksat.
 // The discretisation error is part of the answer: same nodes (h accumulated by repeated += dh).
-template <typename S> __device__ __forceinline__ S geff_literal(const LayerK<S> &l, S theta1, S theta2, int nint) {
+template <typename S, bool EX = false> __device__ __forceinline__ S geff_literal(const LayerK<S> &l, S theta1, S theta2, int nint) {
   using R = real_t<S>;
   S se_i = se_from_theta(l, theta1);
   S se_f = se_from_theta(l, theta2);
-  S h_i = h_from_se(l, se_i);
-  S h_f = h_from_se(l, se_f);
+  S h_i = h_from_se<S, EX>(l, se_i);
+  S h_f = h_from_se<S, EX>(l, se_f);
   S dh = (h_f - h_i) / R(nint);
   S g = S(R(0.0));
-  S k1 = k_from_se(l, se_i);
+  S k1 = k_from_se<S, EX>(l, se_i);
   S h2 = h_i + dh;
   S hdh = dh / R(2.0);
   for (int i = 0; i < nint; i++) {
     // rounding in the repeated h2 += dh can carry the last nodes past 0 (by ~1e-10 in fp64): a negative head is
     // saturation (Se = 1, the |h| < 0.1 rule), never pow of a negative base
-    S se2 = (val(h2) < R(0.0)) ? S(R(1.0)) : se_from_h(l, h2);
-    S k2 = k_from_se(l, se2);
+    S se2 = (val(h2) < R(0.0)) ? S(R(1.0)) : se_from_h<S, EX>(l, h2);
+    S k2 = k_from_se<S, EX>(l, se2);
     g = g + ((k1 + k2) * hdh);
     k1 = k2;
     h2 = h2 + dh;
@@ -197,7 +204,7 @@ template <typename S> __device__ __forceinline__ S geff_literal(const LayerK<S> 
 }
 // the trapezoid the kernels use by default: specialised below for float / double (and the dual numbers, lgar_dual.hpp)
 template <typename S> __device__ __forceinline__ S geff(const LayerK<S> &l, S theta1, S theta2, int nint) {
-  return geff_literal<S>(l, theta1, theta2, nint);
+  return geff_literal<S, false>(l, theta1, theta2, nint);
 }
 
 // fp32 Geff: the same 121 nodes with Se(h) -> K(Se) fused per node.  With a = (alpha h)^n:
@@ -334,7 +341,7 @@ template <> __device__ __forceinline__ double geff<double>(const LayerK<double> 
 // calc_geff with use_closed_form_G (lgar/green_ampt.py:85-98): Brooks-Corey estimate from the van Genuchten parameters
 // (calc_bc_lambda / calc_bc_psib, physics/utils.py:54-64, 84-99).  Operator precedence as written in the reference:
 // geff = h_c * Se_i^e - Se_f^e / (1 - Se_f^e), with Se_f from theta_1 and Se_i from theta_2; inf/nan -> h_c.
-template <typename S> __device__ __forceinline__ S geff_closed(const LayerK<S> &l, S theta1, S theta2) {
+template <typename S, bool EX = false> __device__ __forceinline__ S geff_closed(const LayerK<S> &l, S theta1, S theta2) {
   using R = real_t<S>;
   const S p = R(1.0) + (R(2.0) / l.m);
   const S lambda = R(2.0) / (p - R(3.0));
@@ -344,21 +351,21 @@ template <typename S> __device__ __forceinline__ S geff_closed(const LayerK<S> &
   const S se_i = se_from_theta(l, theta2);
   const S h_c = psib * (R(2.0) + R(3.0) * lambda) / (R(1.0) + R(3.0) * lambda);
   const S e = R(3.0) + R(1.0) / lambda;
-  const S pf = pw(se_f, e);
-  S g = h_c * pw(se_i, e) - pf / (R(1.0) - pf);
+  const S pf = pwx<EX>(se_f, e);
+  S g = h_c * pwx<EX>(se_i, e) - pf / (R(1.0) - pf);
   const R gv = val(g);
   if (gv != gv || gv - gv != R(0.0)) g = h_c;  // torch.isinf / torch.isnan
   return g;
 }
 
 // calc_aet, models/physics/lgar/aet.py:17-51 (0.75: GlobalParams.py:75; clamp upper bound = PET rate)
-template <typename S> __device__ __forceinline__ S aet_fn(const LayerK<S> &l, S pet, real_t<S> dt_h, S psi, real_t<S> wp_psi) {
+template <typename S, bool EX = false> __device__ __forceinline__ S aet_fn(const LayerK<S> &l, S pet, real_t<S> dt_h, S psi, real_t<S> wp_psi) {
   using R = real_t<S>;
   S theta_fc = (l.te - l.tr) * R(0.75) + l.tr;
-  S wp_head_theta = theta_from_h(l, S(wp_psi));
+  S wp_head_theta = theta_from_h<S, EX>(l, S(wp_psi));
   S theta_wp = (theta_fc - wp_head_theta) * R(0.5) + wp_head_theta;
   S se = se_from_theta(l, theta_wp);
-  S psi_wp = h_from_se(l, se);
+  S psi_wp = h_from_se<S, EX>(l, se);
   S r = psi / psi_wp;
   S h_ratio = R(1.0) + r * r * r;
   S a = pet * (R(1.0) / h_ratio) * dt_h;
@@ -404,6 +411,8 @@ template <typename S> struct FrontsView {
 // passes that are provably no-ops between events are skipped (see forward()).
 template <typename S, int NL, int FMAX, int MODE> struct Column {
   using R = real_t<S>;
+  // verification mode in double precision: every pow is the library's correctly rounded one (the reference's torch.pow)
+  static constexpr bool EX = (MODE == 0) && (sizeof(R) == 8);
   const ColParams<S, NL> &P;
   const Glob<R> &G;
   FrontsView<S> F;
@@ -436,9 +445,9 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
 #endif
     if constexpr (MODE == 0 && sizeof(R) == 8) {
       // verification mode: the reference's trapezoid operation by operation (4 pow + sqrt per node, running h)
-      return G.closed_form ? geff_closed(lk, theta1, theta2) : geff_literal(lk, theta1, theta2, G.nint);
+      return G.closed_form ? geff_closed<S, EX>(lk, theta1, theta2) : geff_literal<S, EX>(lk, theta1, theta2, G.nint);
     }
-    return G.closed_form ? geff_closed(lk, theta1, theta2) : geff(lk, theta1, theta2, G.nint);
+    return G.closed_form ? geff_closed<S, EX>(lk, theta1, theta2) : geff(lk, theta1, theta2, G.nint);
   }
   __device__ __forceinline__ S cum_prev(int k) const {  // cum[k-1], 0 for k == 0
     S r = S(R(0.0));
@@ -519,7 +528,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
     const R prior = val(prior_mass);
     R psi = val(psi0);
     R f = val(new_mass) - prior;
-    if (ab(f) <= Tol<R>::mass) return theta_from_h(lk, psi0);
+    if (ab(f) <= Tol<R>::mass) return theta_from_h<S, EX>(lk, psi0);
     R M = R(0.0), dM = R(0.0);
     auto eval = [&](R x) {
       R thk, dthk;
@@ -566,7 +575,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
       if (it == 63) status |= LGAR_ST_ITERCAP;
     }
     const S psi_final = psi0 + (psi - val(psi0));
-    return theta_from_h(lk, psi_final);
+    return theta_from_h<S, EX>(lk, psi_final);
   }
 
   // theta_mass_balance, Layer.py:242-318 (+ recalculate_mass :211-240).  k = the front's layer;
@@ -580,7 +589,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
     S psi_prev = psi;  // a tensor in the reference: psi_prev * 0.1 below carries its gradient
     R delta_mass_prev = delta_mass;
     int count_no_change = 0;
-    if (delta_mass <= Tol<R>::mass) return theta_from_h(lk, psi);
+    if (delta_mass <= Tol<R>::mass) return theta_from_h<S, EX>(lk, psi);
     if constexpr (MODE != 0) return theta_mass_balance_newton(k, lk, psi, new_mass, prior_mass, dth, dthick, dth_k, dthick_k);
     long long it = 0;
     while (delta_mass > Tol<R>::mass) {
@@ -594,12 +603,12 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
         psi = psi - (R(0.1) * factor);
         if (val(psi) < R(0.0) && val(psi_prev) != R(0.0)) psi = psi_prev * R(0.1);
       }
-      theta = theta_from_h(lk, psi);
+      theta = theta_from_h<S, EX>(lk, psi);
       S mass = S(R(0.0));
       mass = mass + (dthick_k * (theta - dth_k));
 #pragma unroll
       for (int j = 0; j < NL - 1; j++)
-        if (j < k) mass = mass + dthick[j] * (theta_from_h(pick_static(P, j), psi) - dth[j]);
+        if (j < k) mass = mass + dthick[j] * (theta_from_h<S, EX>(pick_static(P, j), psi) - dth[j]);
       new_mass = mass;
       delta_mass = ab(val(new_mass) - val(prior_mass));
       if (ab(val(psi) - val(psi_prev)) < Tol<R>::nochange && factor < R(1e-13)) break;
@@ -695,7 +704,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
       if (i < nf0 - 1) {
         if (i == last || feq(i, last)) {
           // deepest front of a layer: psi continuity with the layer below
-          F.TH(i) = theta_from_h(lk, F.PS(i + 1));
+          F.TH(i) = theta_from_h<S, EX>(lk, F.PS(i + 1));
           F.PS(i) = F.PS(i + 1);
         } else if (k == 0) {
           S prior_mass = oc_z * (oc_th - on_th);
@@ -721,12 +730,12 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
           for (int j = 0; j < NL - 1; j++) {
             if (j < k) {
               const LayerK<S> lj = pick_static(P, j);
-              S theta_old = theta_from_h(lj, psi_old);
-              S theta_below_old = theta_from_h(lj, psi_below_old);
+              S theta_old = theta_from_h<S, EX>(lj, psi_old);
+              S theta_below_old = theta_from_h<S, EX>(lj, psi_below_old);
               S lt = P.cum[j] - R(0.0);  // quirk: cumulative thickness (Layer.py:603-604)
               prior_mass = prior_mass + (lt * (theta_old - theta_below_old));
-              S theta = theta_from_h(lj, psi);
-              S theta_below = theta_from_h(lj, psi_below);
+              S theta = theta_from_h<S, EX>(lj, psi);
+              S theta_below = theta_from_h<S, EX>(lj, psi_below);
               new_mass = new_mass + (lt * (theta - theta_below));
               dth[j] = theta_below;
               dthick[j] = lt;
@@ -750,9 +759,9 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
 #pragma unroll
         for (int j = 0; j < NL - 1; j++) {
           const LayerK<S> lj = pick_static(P, j);
-          S theta_old = theta_from_h(lj, psi_old);
+          S theta_old = theta_from_h<S, EX>(lj, psi_old);
           prior_mass = prior_mass + P.thick[j] * (theta_old - R(0.0));
-          S theta = theta_from_h(lj, psi);
+          S theta = theta_from_h<S, EX>(lj, psi);
           new_mass = new_mass + P.thick[j] * (theta - R(0.0));
           dthick[j] = P.thick[j];
         }
@@ -772,7 +781,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
         F.TH(i) = mn(theta_new, lk.te);
         need_psi = true;
       }
-      if (need_psi) F.PS(i) = h_from_se(lk, se_from_theta(lk, F.TH(i)));
+      if (need_psi) F.PS(i) = h_from_se<S, EX>(lk, se_from_theta(lk, F.TH(i)));
       if (i == 0) check_column_mass(fdd, old_mass, infiltration, aet);
       on_z = oc_z; on_th = oc_th; on_ps = oc_ps;
     }
@@ -794,7 +803,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
       S mass = F.Z(i) * (F.TH(i) - F.TH(nx)) + F.Z(nx) * (F.TH(nx) - F.TH(nn));
       F.Z(i) = mass / (F.TH(i) - F.TH(nn));
       S se = se_from_theta(lk, F.TH(i));
-      F.PS(i) = h_from_se(lk, se);
+      F.PS(i) = h_from_se<S, EX>(lk, se);
       // delete_front: the first front of THIS layer's list that is value-equal to `next`
       int j = lo;
       while (j < nf && F.layer(j) == k && !feq(j, nx)) j++;
@@ -826,8 +835,8 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
       const LayerK<S> ln = pick(P, k + 1);
       S overshot = F.Z(i) - F.Z(nx);
       S se = se_from_theta(lk, F.TH(i));
-      F.PS(i) = h_from_se(lk, se);
-      S theta_new = theta_from_h(ln, F.PS(i));
+      F.PS(i) = h_from_se<S, EX>(lk, se);
+      S theta_new = theta_from_h<S, EX>(ln, F.PS(i));
       S mbal = overshot * (F.TH(i) - F.TH(nx));
       S zc = mbal / (theta_new - F.TH(nn));
       S depth_new = cumk + zc;
@@ -856,8 +865,8 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
       flux = (F.TH(i) - F.TH(nx)) * (F.Z(i) - F.Z(nx));
       F.TH(nx) = F.TH(i);
       S se = se_from_theta(lk, F.TH(i));
-      F.PS(nx) = h_from_se(lk, se);
-      k_deepest = k_from_se(lk, se);
+      F.PS(nx) = h_from_se<S, EX>(lk, se);
+      k_deepest = k_from_se<S, EX>(lk, se);
       fdel(i);
     }
     return flux;
@@ -883,14 +892,14 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
         else {
           const int lj = F.layer(found);
           const LayerK<S> lf = pick(P, lj);
-          F.PS(found) = h_from_se(lf, se_from_theta(lf, F.TH(found)));
+          F.PS(found) = h_from_se<S, EX>(lf, se_from_theta(lf, F.TH(found)));
           const S dry_th = F.TH(found), dry_ps = F.PS(found);
           for (int q = 0; q < nf; q++) {
             const int lq = F.layer(q);
             if (lq < lj) {  // quirk: EVERY front of all shallower layers is overwritten (Layer.py:1117-1143)
               const LayerK<S> lql = pick(P, lq);
-              F.PS(q) = h_from_se(lql, se_from_theta(lql, dry_th));
-              F.TH(q) = theta_from_h(lql, dry_ps);
+              F.PS(q) = h_from_se<S, EX>(lql, se_from_theta(lql, dry_th));
+              F.TH(q) = theta_from_h<S, EX>(lql, dry_ps);
             }
           }
         }
@@ -912,13 +921,13 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
   __device__ __forceinline__ void update_psi() {
     for (int i = 0; i < nf - 1; i++) {
       const LayerK<S> lk = pick(P, F.layer(i));
-      F.PS(i) = h_from_se(lk, se_from_theta(lk, F.TH(i)));
+      F.PS(i) = h_from_se<S, EX>(lk, se_from_theta(lk, F.TH(i)));
     }
   }
 
   // K of front i as calc_dzdt / the state dump see it
   __device__ __forceinline__ S front_k(int i, const LayerK<S> &lk) const {
-    S k = k_from_se(lk, se_from_theta(lk, F.TH(i)));
+    S k = k_from_se<S, EX>(lk, se_from_theta(lk, F.TH(i)));
     if (i == 0 && new_front_frozen) k = k * G.frozen;
     return k;
   }
@@ -995,8 +1004,8 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
           for (int j = 0; j < NL - 1; j++)
             if (j < k) {
               const LayerK<S> lj = pick_static(P, j);
-              S tl = theta_from_h(lj, F.PS(i));
-              S kl = k_from_se(lj, se_from_theta(lj, tl));
+              S tl = theta_from_h<S, EX>(lj, F.PS(i));
+              S kl = k_from_se<S, EX>(lj, se_from_theta(lj, tl));
               S pt = (j != 0) ? P.cum[(j > 0) ? j - 1 : 0] : S(R(0.0));
               den = den + ((P.cum[j] - pt) / kl);
             }
@@ -1041,7 +1050,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
     F.Z(0) = dry_depth;
     F.TH(0) = theta_new;
     F.set_flag(0, 0, to_bottom);
-    F.PS(0) = h_from_se(l0, se_from_theta(l0, theta_new));
+    F.PS(0) = h_from_se<S, EX>(l0, se_from_theta(l0, theta_new));
     new_front_frozen = true;
     F.DZ(0) = S(R(0.0));
   }
@@ -1077,8 +1086,8 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
       for (int j = 1; j < NL - 1; j++)
         if (j < kfp) {
           const LayerK<S> lj = pick_static(P, j);
-          S tl = theta_from_h(lj, F.PS(fdd));
-          S kl = k_from_se(lj, se_from_theta(lj, tl));
+          S tl = theta_from_h<S, EX>(lj, F.PS(fdd));
+          S kl = k_from_se<S, EX>(lj, se_from_theta(lj, tl));
           bottom_sum = bottom_sum + ((P.cum[j] - P.cum[j - 1]) / kl);
         }
       f_p = (F.Z(fdd) / bottom_sum) + ((g + h_p) * fd_ksat / F.Z(fdd));
@@ -1113,9 +1122,9 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
     for (int k = 0; k < NL; k++) {
       const LayerK<S> lk = pick_static(P, k);
       F.Z(k) = P.cum[k];
-      F.TH(k) = theta_from_h(lk, S(G.initial_psi));
+      F.TH(k) = theta_from_h<S, EX>(lk, S(G.initial_psi));
       F.PS(k) = S(G.initial_psi);
-      if (k == NL - 1) k_deepest = k_from_se(lk, se_from_theta(lk, F.TH(k)));
+      if (k == NL - 1) k_deepest = k_from_se<S, EX>(lk, se_from_theta(lk, F.TH(k)));
       F.DZ(k) = S(R(0.0));
       F.set_flag(k, k, true);
     }
@@ -1145,7 +1154,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
       const bool create = (val(previous_precip) == R(0.0)) && (val(precip_sub) > R(0.0)) && (val(ponded_water) == R(0.0));
       const int fdd = free_drainage_front();
       const bool saturated = val(F.TH(0)) >= val(P.te[0]);  // Layer.is_saturated, Layer.py:785-793
-      if (val(pet) > R(0.0)) AET_sub = aet_fn(pick_static(P, 0), pet, dt, F.PS(0), G.wp_psi);
+      if (val(pet) > R(0.0)) AET_sub = aet_fn<S, EX>(pick_static(P, 0), pet, dt, F.PS(0), G.wp_psi);
       a_precip = a_precip + precip_sub;
       a_pet = a_pet + ((val(pet_sub) > R(0.0)) ? pet_sub : S(R(0.0)));
       // Single call site for the front move (models/dpLGAR.py:199-266 re-ordered, same data flow): columns

@@ -52,6 +52,16 @@ template <typename R> __device__ __forceinline__ Dual<R> pw(const Dual<R> &x, co
   if (x.v > R(0)) d = v * (y.d * (R(0.6931471805599453) * l2) + y.v * x.d / x.v);
   return Dual<R>(v, d);
 }
+// verification mode (see pwx in lgar_device.hpp): correctly rounded pow / log for the value and the derivative
+template <bool EX, typename R> __device__ __forceinline__ Dual<R> pwx(const Dual<R> &x, const Dual<R> &y) {
+  if constexpr (EX && sizeof(R) == 8) {
+    const R v = pow(x.v, y.v);
+    R d = R(0);
+    if (x.v > R(0)) d = v * (y.d * log(x.v) + y.v * x.d / x.v);
+    return Dual<R>(v, d);
+  }
+  return pw(x, y);
+}
 template <typename R> __device__ __forceinline__ Dual<R> sq(const Dual<R> &x) {
   const R v = sq(x.v);
   return Dual<R>(v, (v > R(0)) ? x.d / (R(2) * v) : R(0));

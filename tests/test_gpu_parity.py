@@ -117,7 +117,8 @@ def test_chunked_run_equals_single_run():
             parts[k].append(o[k])
     for k in full:
         assert torch.equal(torch.cat(parts[k]), full[k]), k
-    assert torch.equal(a.totals, b.totals) and torch.equal(a.depth, b.depth) and torch.equal(a.theta, b.theta)
+    # run totals are accumulated per call and then added: equal up to the last bits; the state itself is bitwise equal
+    assert torch.allclose(a.totals, b.totals, rtol=1e-13, atol=1e-15) and torch.equal(a.depth, b.depth) and torch.equal(a.theta, b.theta)
     # reset() really is set_internal_states: re-running reproduces the first run bitwise
     a.reset()
     again = a.forward(pr, pe, series=("runoff",))
