@@ -19,6 +19,16 @@
 #include "../../include/lgar.h"
 #include "lgar_math.hpp"
 
+// Kernel arguments are read where they are used, as scalar loads from the kernarg segment (constant address space),
+// instead of being held in SGPRs for the whole kernel: the argument block (35 pointers + the run-time constants) is
+// larger than the SGPR file, and everything the register allocator cannot keep becomes v_writelane / v_readlane traffic
+// on the vector ALU -- the unit this kernel is bound by.
+#ifndef LGAR_DEVSIM
+#define LGAR_KARG __attribute__((address_space(4)))
+#else
+#define LGAR_KARG
+#endif
+
 namespace lgar {
 
 constexpr int WAVE = 64;
@@ -68,6 +78,16 @@ __device__ __forceinline__ double ex2(double x) { return exp2(x); }
 #else
 __device__ __forceinline__ double lg2(double x) { return fast_log2(x); }
 __device__ __forceinline__ double ex2(double x) { return fast_exp2(x); }
+#endif
+// log2 / exp2 of arguments known to be positive / not NaN (the interior of the Geff trapezoid): no special-case selects
+__device__ __forceinline__ float lg2p(float x) { return lg2(x); }
+__device__ __forceinline__ float ex2p(float x) { return ex2(x); }
+#ifdef LGAR_F64_LIBM
+__device__ __forceinline__ double lg2p(double x) { return log2(x); }
+__device__ __forceinline__ double ex2p(double x) { return exp2(x); }
+#else
+__device__ __forceinline__ double lg2p(double x) { return fast_log2_core(x); }
+__device__ __forceinline__ double ex2p(double x) { return fast_exp2_core(x); }
 #endif
 __device__ __forceinline__ double sq(double x) { return sqrt(x); }
 __device__ __forceinline__ double ab(double x) { return fabs(x); }
@@ -240,9 +260,9 @@ template <typename S> __device__ __forceinline__ S geff_fused(const LayerK<S> &l
     if (sizeof(R) == 4) h2 = (i + 1 >= nint) ? h_f : h_i + R(i + 1) * dh;
     // four transcendentals per node: P = a^m = x^(n-1), a = x P, sqrt(Se) = (1+a)^(-m/2), (a/(1+a))^m = P Se
     const S x = l.alpha * h2;
-    const S P = ex2(nm1 * lg2(x));
-    const S l1 = lg2(R(1.0) + x * P);
-    const S sqrt_se = ex2(half_m * l1);
+    const S P = ex2p(nm1 * lg2p(x));
+    const S l1 = lg2p(R(1.0) + x * P);
+    const S sqrt_se = ex2p(half_m * l1);
     const S t = R(1.0) - P * (sqrt_se * sqrt_se);
     S k2 = l.ksat * sqrt_se * (t * t);
     k2 = (ab(val(h2)) < R(0.1) || val(h2) < R(0.0)) ? k_sat1 : k2;
@@ -250,7 +270,11 @@ template <typename S> __device__ __forceinline__ S geff_fused(const LayerK<S> &l
     k1 = k2;
     if (sizeof(R) != 4) h2 = h2 + dh;
   }
-  return ab(g / l.ksat);
+  // lg2p / ex2p do not carry NaN: an end point outside the domain (Se > 1 -> negative pow base -> NaN head; the
+  // reference raises ValueError there, physics/utils.py:25-27) must still surface as NaN for the status word
+  const bool outside = is_nan(val(h_i)) || is_nan(val(h_f));
+  const S res = ab(g / l.ksat);
+  return outside ? res + (h_i + h_f) : res;
 }
 // fp32 Geff, lean form (what bench.py measures).  Per node, with x = alpha h and K_r = K / Ksat (Ksat cancels in
 // G = |integral of K dh| / Ksat):
@@ -414,7 +438,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
   // verification mode in double precision: every pow is the library's correctly rounded one (the reference's torch.pow)
   static constexpr bool EX = (MODE == 0) && (sizeof(R) == 8);
   const ColParams<S, NL> &P;
-  const Glob<R> &G;
+  const LGAR_KARG Glob<R> *G;  // run-time constants, in the kernarg segment (re-pointed by the kernel's time loop)
   FrontsView<S> F;
   int nf;
   int status;
@@ -431,7 +455,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
   // accumulators drained every forcing step (physics/MassBalance.py:45-53)
   S a_precip, a_pet, a_aet, a_infil, a_runoff, a_perc, a_giuh, a_disch;
 
-  __device__ Column(const ColParams<S, NL> &p, const Glob<R> &g, const FrontsView<S> &f) : P(p), G(g), F(f) {}
+  __device__ Column(const ColParams<S, NL> &p, const LGAR_KARG Glob<R> *g, const FrontsView<S> &f) : P(p), G(g), F(f) {}
 
   __device__ __forceinline__ S cum_at(int k) const { return sel<S, NL>(P.cum, k); }
   // calc_geff (lgar/green_ampt.py:19-99): trapezoid or closed form, per cfg.data.use_closed_form_G
@@ -439,15 +463,15 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
     if (wave_geff_calls != nullptr && first_active_lane()) *wave_geff_calls += 1u;
 #ifdef LGAR_DUP_GEFF
     if constexpr (sizeof(S) == sizeof(R)) {
-      const S extra = geff(lk, opaque(theta1), opaque(theta2), G.nint);
+      const S extra = geff(lk, opaque(theta1), opaque(theta2), G->nint);
       if (val(extra) == R(12345.678)) return extra;  // practically never true: keeps the duplicate alive
     }
 #endif
     if constexpr (MODE == 0 && sizeof(R) == 8) {
       // verification mode: the reference's trapezoid operation by operation (4 pow + sqrt per node, running h)
-      return G.closed_form ? geff_closed<S, EX>(lk, theta1, theta2) : geff_literal<S, EX>(lk, theta1, theta2, G.nint);
+      return G->closed_form ? geff_closed<S, EX>(lk, theta1, theta2) : geff_literal<S, EX>(lk, theta1, theta2, G->nint);
     }
-    return G.closed_form ? geff_closed<S, EX>(lk, theta1, theta2) : geff(lk, theta1, theta2, G.nint);
+    return G->closed_form ? geff_closed<S, EX>(lk, theta1, theta2) : geff(lk, theta1, theta2, G->nint);
   }
   __device__ __forceinline__ S cum_prev(int k) const {  // cum[k-1], 0 for k == 0
     S r = S(R(0.0));
@@ -593,7 +617,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
     if constexpr (MODE != 0) return theta_mass_balance_newton(k, lk, psi, new_mass, prior_mass, dth, dthick, dth_k, dthick_k);
     long long it = 0;
     while (delta_mass > Tol<R>::mass) {
-      if (++it > G.iter_cap) { status |= LGAR_ST_ITERCAP; break; }
+      if (++it > G->iter_cap) { status |= LGAR_ST_ITERCAP; break; }
       if (val(new_mass) > val(prior_mass)) {
         psi = psi + (R(0.1) * factor);
         switched = false;
@@ -651,7 +675,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
           model = false;
           continue;
         }
-        if (++it > G.iter_cap) { status |= LGAR_ST_ITERCAP; break; }
+        if (++it > G->iter_cap) { status |= LGAR_ST_ITERCAP; break; }
         R before = val(depth_new);
         if (val(current_mass) < val(mass_timestep)) {
           if (jump) {
@@ -709,7 +733,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
         } else if (k == 0) {
           S prior_mass = oc_z * (oc_th - on_th);
           if (i == fdd || feq(fdd, i)) prior_mass = prior_mass + (infiltration - (R(0.0) + aet));
-          S z = F.Z(i) + (F.DZ(i) * G.dt_h);
+          S z = F.Z(i) + (F.DZ(i) * G->dt_h);
           z = mn(z, P.cum[NL - 1]);
           F.Z(i) = z;
           bool zero_dzdt = ab(val(F.DZ(i))) <= R(1e-8);  // torch.isclose(dzdt, 0, rtol=1e-8): atol 1e-8
@@ -720,7 +744,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
           need_psi = true;
         } else {
           S prev_thick = cum_prev(k);
-          S z = F.Z(i) + (F.DZ(i) * G.dt_h);
+          S z = F.Z(i) + (F.DZ(i) * G->dt_h);
           F.Z(i) = z;
           S psi_old = oc_ps, psi_below_old = on_ps;
           S psi = F.PS(i), psi_below = F.PS(i + 1);
@@ -749,7 +773,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
         }
       } else if (nf0 == NL && k == NL - 1) {
         // base_case: one front per layer, uniform psi
-        S z = F.Z(i) + F.DZ(i) * G.dt_h;
+        S z = F.Z(i) + F.DZ(i) * G->dt_h;
         F.Z(i) = z;
         S psi_old = oc_ps;
         S psi = F.PS(i);
@@ -826,7 +850,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
       const S cumk = cum_at(k);
       if (!(val(F.Z(i)) > val(cumk) && val(F.Z(nx)) == val(cumk))) { i++; continue; }
       if (k == NL - 1) {
-        if (G.bottom_mode == 0) { status |= LGAR_ST_BOTTOM; return; }  // reference: AttributeError at Layer.py:980
+        if (G->bottom_mode == 0) { status |= LGAR_ST_BOTTOM; return; }  // reference: AttributeError at Layer.py:980
         i++;  // LGAR-C intent: the bottom layer has no layer below; the domain-boundary step handles this front
         continue;
       }
@@ -928,14 +952,14 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
   // K of front i as calc_dzdt / the state dump see it
   __device__ __forceinline__ S front_k(int i, const LayerK<S> &lk) const {
     S k = k_from_se<S, EX>(lk, se_from_theta(lk, F.TH(i)));
-    if (i == 0 && new_front_frozen) k = k * G.frozen;
+    if (i == 0 && new_front_frozen) k = k * G->frozen;
     return k;
   }
 
   // Does any of the post-sweep passes have work to do?  merge (Layer.py:826-892), layer-boundary crossing (:894-1008),
   // domain-boundary crossing (:1010-1053) and dry-over-wet (:1055-1143) each act only when their trigger holds for some
-  // adjacent pair, and a pass that finds no trigger changes nothing; so when no lane of the wave has a trigger the four
-  // passes are skipped as a block (one cheap scan instead of five).
+  // adjacent pair, and a pass that finds no trigger changes nothing; so a column without a trigger skips the four passes
+  // as a block (one cheap scan instead of five; the wave skips the code when none of its columns has one).
   __device__ __forceinline__ bool front_event_pending() const {
     bool ev = false;
     S z1 = F.Z(0), t1 = F.TH(0);
@@ -958,12 +982,13 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
   __device__ __forceinline__ S move_wetting_front(S infiltration, S &aet, S old_mass, int fdd) {
     move_sweep(infiltration, aet, old_mass, fdd);
     S bottom_flux = S(R(0.0));
-    if (any_lane(front_event_pending()) != 0ull) {
+    // (a per-lane decision: a column's results must not depend on which other columns share its wave)
+    if (front_event_pending()) {
       for (int pass = 0; pass < 2; pass++) {
         merge_fronts();
         if (pass == 0) cross_layer_boundary();
       }
-      if (G.bottom_mode != 0) bottom_flux = cross_domain_boundary();
+      if (G->bottom_mode != 0) bottom_flux = cross_domain_boundary();
       S mass_change = fix_dry_over_wet();
       if (ab(val(mass_change)) > R(1e-7)) aet = aet - mass_change;
       // the passes can leave psi inconsistent with theta (dry-over-wet in a deeper layer writes the psi of ANOTHER
@@ -1020,7 +1045,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
   __device__ __forceinline__ S calc_dry_depth() {
     const LayerK<S> l0 = pick_static(P, 0);
     S delta_theta = l0.te - F.TH(0);
-    S tau = G.dt_h * l0.ksat / delta_theta;
+    S tau = G->dt_h * l0.ksat / delta_theta;
     S g = capillary_drive(l0, F.TH(0), l0.te);
     if (is_nan(val(g))) status |= LGAR_ST_NAN;
     S dry = R(0.5) * (tau + sq(tau * tau + R(4.0) * tau * g));
@@ -1058,7 +1083,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
   // insert_water, Layer.py:1418-1536 (get_drainage_neighbors :1584-1607, calc_bottom_sum_f_p :1538-1555):
   // Green-Ampt infiltration capacity f_p and the infiltration / runoff / ponding split
   __device__ __forceinline__ void insert_water(int fdd, S precip, S &ponded, S &infiltration, S &runoff) {
-    const R dt = G.dt_h;
+    const R dt = G->dt_h;
     S h_p = (ponded - precip) * dt;
     if (val(h_p) < R(0.0)) h_p = S(R(0.0));
     const int kfp = F.layer(fdd);
@@ -1067,7 +1092,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
     const int nxt_i = lo + 1;  // the front after the FIRST front of the free-drainage front's layer (quirk)
     // reference: AttributeError (Layer.py:1606) when the free-drainage front is the lone front of the bottom layer.
     // With one front per layer no neighbour is needed (Geff = 0); bottom_mode 1 lets that case through.
-    if (nxt_i >= nf && (nf != NL || G.bottom_mode == 0)) { status |= LGAR_ST_STRUCT; return; }
+    if (nxt_i >= nf && (nf != NL || G->bottom_mode == 0)) { status |= LGAR_ST_STRUCT; return; }
     const LayerK<S> lk = pick(P, kfp);
     S g = S(R(0.0));
     // quirk: with a fully saturated one-front top layer right after a layer crossing, nxt_i is a front of the
@@ -1079,9 +1104,9 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
     if (kfp == 0) {
       f_p = P.ksat[0] * (R(1.0) + (g + h_p) / F.Z(fdd));
     } else {
-      S fd_ksat = lk.ksat * G.frozen;
+      S fd_ksat = lk.ksat * G->frozen;
       S bottom_sum = (F.Z(fdd) - cum_prev(kfp)) / fd_ksat;
-      bottom_sum = bottom_sum + ((P.cum[0] - R(0.0)) / (P.ksat[0] * G.frozen));
+      bottom_sum = bottom_sum + ((P.cum[0] - R(0.0)) / (P.ksat[0] * G->frozen));
 #pragma unroll
       for (int j = 1; j < NL - 1; j++)
         if (j < kfp) {
@@ -1095,20 +1120,20 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
     S pond_temp = ponded - f_p * dt;
     if (val(pond_temp) < R(0.0)) pond_temp = S(R(0.0));
     S fp_cm = f_p * dt;
-    if (G.pdm > R(0.0)) {
-      if (val(pond_temp) < G.pdm) {
+    if (G->pdm > R(0.0)) {
+      if (val(pond_temp) < G->pdm) {
         infiltration = mn(ponded, fp_cm);
         ponded = ponded - infiltration;
-      } else if (val(pond_temp) > G.pdm) {
-        ponded = S(G.pdm);
+      } else if (val(pond_temp) > G->pdm) {
+        ponded = S(G->pdm);
         infiltration = fp_cm;
       }
-      S r = pond_temp - G.pdm;
+      S r = pond_temp - G->pdm;
       runoff = (val(r) > R(0.0)) ? r : S(R(0.0));
     } else {
       infiltration = mn(ponded, fp_cm);
       S r = ponded - infiltration;
-      ponded = S(G.pdm);
+      ponded = S(G->pdm);
       runoff = (val(r) > R(0.0)) ? r : S(R(0.0));
     }
   }
@@ -1122,8 +1147,8 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
     for (int k = 0; k < NL; k++) {
       const LayerK<S> lk = pick_static(P, k);
       F.Z(k) = P.cum[k];
-      F.TH(k) = theta_from_h<S, EX>(lk, S(G.initial_psi));
-      F.PS(k) = S(G.initial_psi);
+      F.TH(k) = theta_from_h<S, EX>(lk, S(G->initial_psi));
+      F.PS(k) = S(G->initial_psi);
       if (k == NL - 1) k_deepest = k_from_se<S, EX>(lk, se_from_theta(lk, F.TH(k)));
       F.DZ(k) = S(R(0.0));
       F.set_flag(k, k, true);
@@ -1141,9 +1166,9 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
 
   // dpLGAR.forward, models/dpLGAR.py:154-299: one forcing step = nsub sub-steps
   __device__ __forceinline__ void forward(S precip, S pet) {
-    const R dt = G.dt_h;
+    const R dt = G->dt_h;
     S ending_volume_sub = ending_volume;
-    for (int sub = 0; sub < G.nsub; sub++) {
+    for (int sub = 0; sub < G->nsub; sub++) {
       if (status & (LGAR_ST_BOTTOM | LGAR_ST_OVERFLOW | LGAR_ST_STRUCT)) return;  // dead column
       new_front_frozen = false;
       S precip_sub = precip * dt;
@@ -1154,7 +1179,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
       const bool create = (val(previous_precip) == R(0.0)) && (val(precip_sub) > R(0.0)) && (val(ponded_water) == R(0.0));
       const int fdd = free_drainage_front();
       const bool saturated = val(F.TH(0)) >= val(P.te[0]);  // Layer.is_saturated, Layer.py:785-793
-      if (val(pet) > R(0.0)) AET_sub = aet_fn<S, EX>(pick_static(P, 0), pet, dt, F.PS(0), G.wp_psi);
+      if (val(pet) > R(0.0)) AET_sub = aet_fn<S, EX>(pick_static(P, 0), pet, dt, F.PS(0), G->wp_psi);
       a_precip = a_precip + precip_sub;
       a_pet = a_pet + ((val(pet_sub) > R(0.0)) ? pet_sub : S(R(0.0)));
       // Single call site for the front move (models/dpLGAR.py:199-266 re-ordered, same data flow): columns
@@ -1179,13 +1204,13 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
       }
       if (!inserting) {
         // update_ponded_depth, models/dpLGAR.py:369-382
-        if (val(ponded_depth_sub) < G.pdm) {
+        if (val(ponded_depth_sub) < G->pdm) {
           runoff_sub = S(R(0.0));
           ponded_water_sub = ponded_depth_sub;
           ponded_depth_sub = S(R(0.0));
         } else {
-          runoff_sub = ponded_depth_sub - G.pdm;
-          ponded_depth_sub = S(G.pdm);
+          runoff_sub = ponded_depth_sub - G->pdm;
+          ponded_depth_sub = S(G->pdm);
           ponded_water_sub = ponded_depth_sub;
           a_runoff = a_runoff + runoff_sub;
         }
@@ -1204,13 +1229,13 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
       // GIUH, models/dpLGAR.py:292-298 and lgar/giuh.py:8-20
       R qsum = R(0.0);
 #pragma unroll
-      for (int i = 0; i < LGAR_GMAX; i++) if (i < G.ng) qsum += val(giuh_q[i]);
+      for (int i = 0; i < LGAR_GMAX; i++) if (i < G->ng) qsum += val(giuh_q[i]);
       if (qsum > R(0.0) || val(runoff_sub) > R(0.0)) {
 #pragma unroll
-        for (int i = 0; i < LGAR_GMAX; i++) if (i < G.ng) giuh_q[i] = giuh_q[i] + (G.giuh[i] * runoff_sub);
+        for (int i = 0; i < LGAR_GMAX; i++) if (i < G->ng) giuh_q[i] = giuh_q[i] + (G->giuh[i] * runoff_sub);
         S now = giuh_q[0];
 #pragma unroll
-        for (int i = 0; i < LGAR_GMAX - 1; i++) giuh_q[i] = (i < G.ng - 1) ? giuh_q[i + 1] : S(R(0.0));
+        for (int i = 0; i < LGAR_GMAX - 1; i++) giuh_q[i] = (i < G->ng - 1) ? giuh_q[i + 1] : S(R(0.0));
         giuh_q[LGAR_GMAX - 1] = S(R(0.0));
         a_giuh = a_giuh + now;
         a_disch = a_disch + now;

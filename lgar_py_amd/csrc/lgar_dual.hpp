@@ -83,6 +83,8 @@ template <typename R> __device__ __forceinline__ Dual<R> ex2(const Dual<R> &y) {
   const R v = ex2(y.v);
   return Dual<R>(v, v * R(0.6931471805599453) * y.d);
 }
+template <typename R> __device__ __forceinline__ Dual<R> lg2p(const Dual<R> &x) { return lg2(x); }
+template <typename R> __device__ __forceinline__ Dual<R> ex2p(const Dual<R> &y) { return ex2(y); }
 #ifndef LGAR_NO_FUSED_GEFF
 template <> __device__ __forceinline__ Dual<double> geff<Dual<double>>(const LayerK<Dual<double>> &l, Dual<double> t1,
                                                                        Dual<double> t2, int nint) {

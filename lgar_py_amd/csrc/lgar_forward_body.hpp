@@ -55,8 +55,21 @@ __device__ __forceinline__ void atomic_add(double *p, double v) { *p += v; }
 __device__ __forceinline__ void atomic_add(unsigned long long *p, unsigned long long v) { *p += v; }
 #endif
 
+// the kernel's argument block where it lies (kernarg segment); `launder` makes the compiler forget what it has already
+// loaded through the pointer, so values needed again later are re-read (one scalar load) rather than kept or spilled
+#ifndef LGAR_DEVSIM
+template <typename T> __device__ __forceinline__ const LGAR_KARG T *launder(const LGAR_KARG T *p) {
+  const unsigned long long v = (unsigned long long)p;
+  unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  asm volatile("" : "+s"(lo), "+s"(hi));
+  return (const LGAR_KARG T *)(((unsigned long long)hi << 32) | lo);
+}
+#else
+template <typename T> __device__ __forceinline__ const T *launder(const T *p) { return p; }
+#endif
+
 template <typename R, int NL>
-__device__ __forceinline__ void load_params(const KArgs<R> &a, size_t c, ColParams<R, NL> &P) {
+__device__ __forceinline__ void load_params(const LGAR_KARG KArgs<R> &a, size_t c, ColParams<R, NL> &P) {
   const size_t N = (size_t)a.N;
 #pragma unroll
   for (int k = 0; k < NL; k++) {
@@ -86,7 +99,7 @@ template <typename S> __device__ __forceinline__ FrontsView<S> make_view(S *f, u
 
 // state LDS/registers -> HBM.  Rows [0, nf) are written, rows [nf, nf_before) (fronts that disappeared) are zeroed.
 template <typename R, int NL, int FMAX, int MODE>
-__device__ __forceinline__ void store_state(const KArgs<R> &a, size_t c, const Column<R, NL, FMAX, MODE> &col, int nf_before,
+__device__ __forceinline__ void store_state(const LGAR_KARG KArgs<R> &a, size_t c, const Column<R, NL, FMAX, MODE> &col, int nf_before,
                                             int status_word) {
   const size_t N = (size_t)a.N;
   const int rows = (col.nf > nf_before ? col.nf : nf_before) < a.F ? (col.nf > nf_before ? col.nf : nf_before) : a.F;
@@ -110,10 +123,11 @@ __device__ __forceinline__ void store_state(const KArgs<R> &a, size_t c, const C
 
 // dpLGAR.set_internal_states (models/dpLGAR.py:97-147) for one column
 template <typename R, int NL, int FMAX>
-__device__ __forceinline__ void init_lane(const KArgs<R> &a, size_t c, int lane, WaveLDS<R, FMAX> &lds) {
+__device__ __forceinline__ void init_lane(const LGAR_KARG KArgs<R> *ap, size_t c, int lane, WaveLDS<R, FMAX> &lds) {
+  const LGAR_KARG KArgs<R> &a = *ap;
   ColParams<R, NL> P;
   load_params<R, NL>(a, c, P);
-  Column<R, NL, FMAX, 1> col(P, a.G, make_view<R>(&lds.f[0][0][0], &lds.fl[0][0], FMAX, lane));
+  Column<R, NL, FMAX, 1> col(P, &ap->G, make_view<R>(&lds.f[0][0][0], &lds.fl[0][0], FMAX, lane));
   col.init_state();
   const int nf_before = a.nf[c];
   store_state<R, NL, FMAX, 1>(a, c, col, nf_before < 0 ? 0 : nf_before, 0);
@@ -126,7 +140,9 @@ __device__ __forceinline__ void init_lane(const KArgs<R> &a, size_t c, int lane,
 // `live` = false for the padding lanes of a ragged tail wave: they integrate a copy of the last column (all 64 lanes stay
 // active for the wave reductions) and store nothing.
 template <typename R, int NL, int FMAX, int MODE>
-__device__ __forceinline__ void forward_lane(const KArgs<R> &a, size_t c, bool live, int lane, WaveLDS<R, FMAX> &lds) {
+__device__ __forceinline__ void forward_lane(const LGAR_KARG KArgs<R> *ap, size_t c, bool live, int lane,
+                                             WaveLDS<R, FMAX> &lds) {
+  const LGAR_KARG KArgs<R> &a = *ap;
   const size_t N = (size_t)a.N;
   const bool basin_on = (a.basin != nullptr) && (a.basin_mask != 0u);
   int status = a.status[c];
@@ -141,7 +157,7 @@ __device__ __forceinline__ void forward_lane(const KArgs<R> &a, size_t c, bool l
   const bool mine = t_begin < a.T;
   ColParams<R, NL> P;
   load_params<R, NL>(a, c, P);
-  Column<R, NL, FMAX, MODE> col(P, a.G, make_view<R>(&lds.f[0][0][0], &lds.fl[0][0], FMAX, lane));
+  Column<R, NL, FMAX, MODE> col(P, &ap->G, make_view<R>(&lds.f[0][0][0], &lds.fl[0][0], FMAX, lane));
   // state HBM -> LDS / registers
   const int nf_stored = a.nf[c];
   const int cap = FMAX < a.F ? FMAX : a.F;
@@ -187,11 +203,15 @@ __device__ __forceinline__ void forward_lane(const KArgs<R> &a, size_t c, bool l
   // hides under ~10^4 cycles of VALU work
   R precip_nx = a.T > 0 ? a.precip[c] : R(0);
   R pet_nx = a.T > 0 ? a.pet[c] : R(0);
-  for (int t = 0; t < a.T; t++) {
+  const int T = a.T;
+  for (int t = 0; t < T; t++) {
+    ap = launder(ap);
+    const LGAR_KARG KArgs<R> &a = *ap;  // (shadows the outer reference on purpose)
+    col.G = &ap->G;
     const size_t o = (size_t)t * N + c;
     const R precip = precip_nx;
     const R pet = pet_nx;
-    if (t + 1 < a.T) {
+    if (t + 1 < T) {
       precip_nx = a.precip[o + N];
       pet_nx = a.pet[o + N];
     }
@@ -218,7 +238,7 @@ __device__ __forceinline__ void forward_lane(const KArgs<R> &a, size_t c, bool l
       for (int j = 0; j < LGAR_NACC; j++)
         if (a.basin_mask & (1u << j)) {
           const double s = wave_sum(w * (double)acc[j]);
-          if (lane == 0) atomic_add(&a.basin[(size_t)j * a.T + t], s);
+          if (lane == 0) atomic_add(&a.basin[(size_t)j * T + t], s);
         }
     }
     if (active) {
@@ -227,35 +247,37 @@ __device__ __forceinline__ void forward_lane(const KArgs<R> &a, size_t c, bool l
       col.drain();
     }
   }
-  if (a.counters != nullptr) {
+  ap = launder(ap);
+  const LGAR_KARG KArgs<R> &z = *ap;  // the epilogue re-reads what it needs
+  if (z.counters != nullptr) {
     // measurement: wave-level Geff evaluations (the dominant instruction stream) of this launch
-    if (lane == 0 && lds.geff_calls) atomic_add(&a.counters[0], (unsigned long long)lds.geff_calls);
+    if (lane == 0 && lds.geff_calls) atomic_add(&z.counters[0], (unsigned long long)lds.geff_calls);
   }
   if (!live || !mine) return;
   int word = col.status;
-  if (t_handover < a.T) word |= LGAR_ST_RESUME | (int)((unsigned)t_handover << LGAR_ST_STEP_SHIFT);
+  if (t_handover < z.T) word |= LGAR_ST_RESUME | (int)((unsigned)t_handover << LGAR_ST_STEP_SHIFT);
   if (untouched) {
-    a.status[c] = word;
-    if (a.call_sums != nullptr && a.chain_first) {
+    z.status[c] = word;
+    if (z.call_sums != nullptr && z.chain_first) {
 #pragma unroll
-      for (int j = 0; j < 8; j++) a.call_sums[j * N + c] = R(0);
-      a.call_sums[8 * N + c] = col.ponded_water;
-      a.call_sums[9 * N + c] = col.ending_volume;
+      for (int j = 0; j < 8; j++) z.call_sums[j * N + c] = R(0);
+      z.call_sums[8 * N + c] = col.ponded_water;
+      z.call_sums[9 * N + c] = col.ending_volume;
     }
     return;
   }
-  store_state<R, NL, FMAX, MODE>(a, c, col, nf_before, word);
+  store_state<R, NL, FMAX, MODE>(z, c, col, nf_before, word);
 #pragma unroll
-  for (int j = 0; j < 8; j++) a.totals[j * N + c] = a.totals[j * N + c] + tot[j];  // MassBalance's run totals
-  a.totals[8 * N + c] = col.ponded_water;
-  a.totals[9 * N + c] = col.ending_volume;
-  if (a.call_sums != nullptr) {
+  for (int j = 0; j < 8; j++) z.totals[j * N + c] = z.totals[j * N + c] + tot[j];  // MassBalance's run totals
+  z.totals[8 * N + c] = col.ponded_water;
+  z.totals[9 * N + c] = col.ending_volume;
+  if (z.call_sums != nullptr) {
     // a column handed over by an earlier kernel of the chain already has its first part in place
-    const bool add = !a.chain_first;
+    const bool add = !z.chain_first;
 #pragma unroll
-    for (int j = 0; j < 8; j++) a.call_sums[j * N + c] = add ? a.call_sums[j * N + c] + tot[j] : tot[j];
-    a.call_sums[8 * N + c] = col.ponded_water;
-    a.call_sums[9 * N + c] = col.ending_volume;
+    for (int j = 0; j < 8; j++) z.call_sums[j * N + c] = add ? z.call_sums[j * N + c] + tot[j] : tot[j];
+    z.call_sums[8 * N + c] = col.ponded_water;
+    z.call_sums[9 * N + c] = col.ending_volume;
   }
 }
 

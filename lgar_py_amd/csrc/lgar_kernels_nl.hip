@@ -22,9 +22,15 @@
 namespace lgar {
 
 // waves per SIMD the register allocator has to make room for
+#ifndef LGAR_OCC_F32_SMALL
+#define LGAR_OCC_F32_SMALL 4
+#endif
+#ifndef LGAR_OCC_F64_SMALL
+#define LGAR_OCC_F64_SMALL 2
+#endif
 template <typename R, int CAP> struct Occupancy {
-  static constexpr int waves = (sizeof(R) == 4) ? ((CAP <= LGAR_CAP_SMALL) ? 4 : ((CAP <= LGAR_CAP_MID) ? 2 : 1))
-                                                : ((CAP <= LGAR_CAP_SMALL) ? 2 : 1);
+  static constexpr int waves = (sizeof(R) == 4) ? ((CAP <= LGAR_CAP_SMALL) ? LGAR_OCC_F32_SMALL : ((CAP <= LGAR_CAP_MID) ? 2 : 1))
+                                                : ((CAP <= LGAR_CAP_SMALL) ? LGAR_OCC_F64_SMALL : 1);
 };
 
 template <typename R, int NL, int CAP>
@@ -33,7 +39,7 @@ __global__ __launch_bounds__(WAVE) void lgar_init_kernel(KArgs<R> a) {
   const int lane = threadIdx.x;
   const size_t c = (size_t)blockIdx.x * WAVE + lane;
   if (c >= (size_t)a.N) return;
-  init_lane<R, NL, CAP>(a, c, lane, lds);
+  init_lane<R, NL, CAP>((const LGAR_KARG KArgs<R> *)__builtin_amdgcn_kernarg_segment_ptr(), c, lane, lds);
 }
 
 template <typename R, int NL, int CAP, int MODE>
@@ -43,7 +49,9 @@ __global__ __launch_bounds__(WAVE, (Occupancy<R, CAP>::waves)) void lgar_forward
   const size_t N = (size_t)a.N;
   const size_t c0 = (size_t)blockIdx.x * WAVE + lane;
   const bool live = c0 < N;
-  forward_lane<R, NL, CAP, MODE>(a, live ? c0 : N - 1, live, lane, lds);
+  // the argument block is read in place (kernarg segment), see LGAR_KARG in lgar_device.hpp
+  forward_lane<R, NL, CAP, MODE>((const LGAR_KARG KArgs<R> *)__builtin_amdgcn_kernarg_segment_ptr(), live ? c0 : N - 1, live,
+                                 lane, lds);
 }
 
 template <typename R>

@@ -1,9 +1,18 @@
 // lgar_math.hpp -- lean double-precision log2 / exp2 / pow for the fp64 LGAR kernels.
 //
 // ocml's pow/log2/exp2 are < 1 ulp but built on double-double arithmetic (~100-200 instructions each); the LGAR path
-// evaluates ~1.5 k of them per column-timestep.  These versions are ~2 ulp (relative 3e-16 on log2/exp2, ~1e-14 on
-// pow for the exponents used here) in ~20-30 instructions: frexp + atanh series for log2, round-to-nearest + Taylor +
-// ldexp for exp2.  That is nine orders of magnitude inside the 1e-6 parity bar; -DLGAR_F64_LIBM restores ocml.
+// evaluates ~1.5 k of them per column-timestep (the fp64 kernel spends ~88 % of its time in the Geff trapezoid, four of
+// these per node).  The versions here take ~20 instructions each:
+//   exp2: round-to-nearest split x = k + f, |f| <= 1/2, degree-11 near-minimax polynomial for 2^f (|error| <= 3.2e-18),
+//         ldexp;
+//   log2: x = m 2^e with m in [sqrt(1/2), sqrt(2)) (e from the exponent of x sqrt(2): no renormalisation selects),
+//         s = (m - 1)/(m + 1), |s| <= 0.1716, log2 m = s Q(s^2) with Q a degree-7 near-minimax polynomial for
+//         (2/ln 2) atanh(s)/s (|error| <= 3.4e-18); the quotient by v_rcp_f64 + one Newton step instead of the
+//         ~12-instruction IEEE divide.
+// Both are good to ~2.5e-16 (relative; log2 relative to max(1, |log2 x|), and relative to its own value near x = 1),
+// i.e. pow is good to ~max(1, |y log2 x|) * 7e-16 relative, nine orders of magnitude inside the 1e-6 parity bar.
+// The polynomial coefficients were fitted with mpmath.chebyfit at 60 digits (tests/test_device_math.py re-derives the
+// error bounds); -DLGAR_F64_LIBM restores ocml.  search_mode 0 (verification) uses the library pow instead (pwx).
 #pragma once
 #ifndef LGAR_DEVSIM
 #include <hip/hip_runtime.h>
@@ -11,36 +20,40 @@
 
 namespace lgar {
 
-// 2^x
-__device__ __forceinline__ double fast_exp2(double x) {
+// 2^x for finite x and -inf .. +inf clamped; NaN is NOT preserved (callers that need NaN to survive use fast_exp2)
+__device__ __forceinline__ double fast_exp2_core(double x) {
   const double xc = fmin(fmax(x, -1100.0), 1100.0);  // keeps the integer part in range; ldexp saturates to 0 / inf
   const double k = rint(xc);
-  const double f = (xc - k) * 0.6931471805599453094;  // |f| <= 0.3466
-  double p = 1.6059043836821613e-10;                   // 1/13!
-  p = fma(p, f, 2.08767569878681e-09);                 // 1/12!
-  p = fma(p, f, 2.505210838544172e-08);                // 1/11!
-  p = fma(p, f, 2.755731922398589e-07);                // 1/10!
-  p = fma(p, f, 2.7557319223985893e-06);               // 1/9!
-  p = fma(p, f, 2.48015873015873e-05);                 // 1/8!
-  p = fma(p, f, 1.984126984126984e-04);                // 1/7!
-  p = fma(p, f, 1.388888888888889e-03);                // 1/6!
-  p = fma(p, f, 8.333333333333333e-03);                // 1/5!
-  p = fma(p, f, 4.1666666666666664e-02);               // 1/4!
-  p = fma(p, f, 1.6666666666666666e-01);               // 1/3!
-  p = fma(p, f, 0.5);
+  const double f = xc - k;  // |f| <= 0.5, exact
+  double p = 4.45581790833606449e-10;
+  p = fma(p, f, 7.07419429728852106e-09);
+  p = fma(p, f, 1.01780570877339407e-07);
+  p = fma(p, f, 1.32154325359123753e-06);
+  p = fma(p, f, 1.52527338415567733e-05);
+  p = fma(p, f, 1.54035304637243530e-04);
+  p = fma(p, f, 1.33335581464064708e-03);
+  p = fma(p, f, 9.61812910758725638e-03);
+  p = fma(p, f, 5.55041086648216248e-02);
+  p = fma(p, f, 2.40226506959101582e-01);
+  p = fma(p, f, 6.93147180559945286e-01);
   p = fma(p, f, 1.0);
-  p = fma(p, f, 1.0);
-  const double r = ldexp(p, (int)k);
+  return ldexp(p, (int)k);
+}
+
+// 2^x, NaN in -> NaN out
+__device__ __forceinline__ double fast_exp2(double x) {
+  const double r = fast_exp2_core(x);
   return (x != x) ? x : r;
 }
 
-// log2(x): -inf at 0, NaN below 0 / for NaN, +inf at +inf
-__device__ __forceinline__ double fast_log2(double x) {
+// log2(x) for positive finite x (anything else: unspecified, no trap)
+__device__ __forceinline__ double fast_log2_core(double x) {
+  // x = m 2^e with m in [sqrt(1/2), sqrt(2)): e = exponent of x sqrt(2) (no compare-and-select renormalisation), so
+  // x near 1 gives e = 0 and a tiny s: the result is accurate RELATIVE to itself there (1 - Se^(1/m) in K(Se) needs that)
   int e;
-  double m = frexp(x, &e);  // m in [0.5, 1)
-  const bool lo = m < 0.70710678118654752440;
-  m = lo ? m * 2.0 : m;     // m in [sqrt(1/2), sqrt(2))
-  e = lo ? e - 1 : e;
+  (void)frexp(x * 1.41421356237309515, &e);
+  e -= 1;
+  const double m = ldexp(x, -e);
   // (m - 1) / (m + 1) with v_rcp_f64 + one Newton step instead of the ~12-instruction IEEE divide
   const double d = m + 1.0;
 #ifndef LGAR_DEVSIM
@@ -51,19 +64,20 @@ __device__ __forceinline__ double fast_log2(double x) {
   rc = fma(fma(-d, rc, 1.0), rc, rc);
   const double s = (m - 1.0) * rc;  // |s| <= 0.1716
   const double z = s * s;
-  double p = 4.7619047619047616e-02;        // 1/21
-  p = fma(p, z, 5.2631578947368418e-02);    // 1/19
-  p = fma(p, z, 5.8823529411764705e-02);    // 1/17
-  p = fma(p, z, 6.6666666666666666e-02);    // 1/15
-  p = fma(p, z, 7.6923076923076927e-02);    // 1/13
-  p = fma(p, z, 9.0909090909090912e-02);    // 1/11
-  p = fma(p, z, 1.1111111111111111e-01);    // 1/9
-  p = fma(p, z, 1.4285714285714285e-01);    // 1/7
-  p = fma(p, z, 0.2);
-  p = fma(p, z, 3.3333333333333331e-01);
-  p = fma(p, z, 1.0);
-  const double lnm = 2.0 * s * p;            // ln(m) = 2 atanh(s)
-  double r = fma(lnm, 1.4426950408889634074, (double)e);
+  double q = 2.13658959211262989e-01;
+  q = fma(q, z, 2.20913084014299627e-01);
+  q = fma(q, z, 2.62334352512281266e-01);
+  q = fma(q, z, 3.20598534913810962e-01);
+  q = fma(q, z, 4.12198585840901910e-01);
+  q = fma(q, z, 5.77078016345520250e-01);
+  q = fma(q, z, 9.61796693925989765e-01);
+  q = fma(q, z, 2.88539008177792677e+00);
+  return fma(s, q, (double)e);
+}
+
+// log2(x): -inf at 0, NaN below 0 / for NaN, +inf at +inf
+__device__ __forceinline__ double fast_log2(double x) {
+  double r = fast_log2_core(x);
   r = (x == 0.0) ? -__builtin_huge_val() : r;
   r = (x < 0.0 || x != x) ? __builtin_nan("") : r;
   r = (x == __builtin_huge_val()) ? x : r;

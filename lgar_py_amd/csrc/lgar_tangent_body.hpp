@@ -29,8 +29,9 @@ template <typename R> struct TArgs {
 };
 
 template <typename R, int NL, int FMAX, int MODE>
-__device__ __forceinline__ void tangent_lane(const TArgs<R> &a, size_t c, int lane, WaveLDS<Dual<R>, FMAX> &lds) {
+__device__ __forceinline__ void tangent_lane(const LGAR_KARG TArgs<R> *ap, size_t c, int lane, WaveLDS<Dual<R>, FMAX> &lds) {
   using S = Dual<R>;
+  const LGAR_KARG TArgs<R> &a = *ap;
   const size_t N = (size_t)a.N;
   if (!a.chain_first) {
     const bool mine = (a.status[c] & LGAR_ST_RESUME) != 0;
@@ -53,7 +54,7 @@ __device__ __forceinline__ void tangent_lane(const TArgs<R> &a, size_t c, int la
     P.inv_n[k] = R(1.0) / P.n[k];
     P.cum[k] = (k == 0) ? P.thick[0] : P.cum[(k > 0) ? k - 1 : 0] + P.thick[k];
   }
-  Column<S, NL, FMAX, MODE> col(P, a.G, make_view<S>(&lds.f[0][0][0], &lds.fl[0][0], FMAX, lane));
+  Column<S, NL, FMAX, MODE> col(P, &ap->G, make_view<S>(&lds.f[0][0][0], &lds.fl[0][0], FMAX, lane));
   col.init_state();
   R grad = R(0);
   bool handed_over = false;

@@ -17,7 +17,7 @@ template <typename R, int NL, int CAP, int MODE> __global__ __launch_bounds__(WA
   const int lane = threadIdx.x;
   const size_t c = (size_t)blockIdx.x * WAVE + lane;
   if (c >= (size_t)a.N) return;
-  tangent_lane<R, NL, CAP, MODE>(a, c, lane, lds);
+  tangent_lane<R, NL, CAP, MODE>((const LGAR_KARG TArgs<R> *)__builtin_amdgcn_kernarg_segment_ptr(), c, lane, lds);
 }
 
 template <typename R, int NL, int CAP, int MODE> static void launch_one(const TArgs<R> &a, unsigned grid, hipStream_t st) {

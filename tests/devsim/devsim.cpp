@@ -54,7 +54,7 @@ KArgs<R> make_args(const LgarDims *d, const LgarParams *p, LgarState *s, const L
 
 template <typename R, int NL, int CAP, int MODE> void run_forward(const KArgs<R> &a) {
   std::vector<WaveLDS<R, CAP>> lds(1);
-  for (int c = 0; c < a.N; c++) forward_lane<R, NL, CAP, MODE>(a, (size_t)c, true, 0, lds[0]);
+  for (int c = 0; c < a.N; c++) forward_lane<R, NL, CAP, MODE>(&a, (size_t)c, true, 0, lds[0]);
 }
 
 template <typename R, int NL>
@@ -80,13 +80,13 @@ int forward_typed(const LgarDims *d, const LgarParams *p, LgarState *s, const Lg
 template <typename R, int NL> int init_typed(const LgarDims *d, const LgarParams *p, LgarState *s, int32_t *status) {
   KArgs<R> a = make_args<R>(d, p, s, nullptr, nullptr, status);
   std::vector<WaveLDS<R, LGAR_CAP_SMALL>> lds(1);
-  for (int c = 0; c < a.N; c++) init_lane<R, NL, LGAR_CAP_SMALL>(a, (size_t)c, 0, lds[0]);
+  for (int c = 0; c < a.N; c++) init_lane<R, NL, LGAR_CAP_SMALL>(&a, (size_t)c, 0, lds[0]);
   return 0;
 }
 
 template <typename R, int NL, int CAP, int MODE> void run_tangent(const TArgs<R> &a) {
   std::vector<WaveLDS<Dual<R>, CAP>> lds(1);
-  for (int c = 0; c < a.N; c++) tangent_lane<R, NL, CAP, MODE>(a, (size_t)c, 0, lds[0]);
+  for (int c = 0; c < a.N; c++) tangent_lane<R, NL, CAP, MODE>(&a, (size_t)c, 0, lds[0]);
 }
 
 template <typename R, int NL>
@@ -112,6 +112,19 @@ int tangent_typed(const LgarDims *d, const LgarParams *p, const LgarParams *dir,
 #endif
 
 extern "C" {
+
+// element-wise access to the lean fp64 math (lgar_math.hpp): op 0 exp2, 1 log2, 2 pow(x, y), 3 exp2_core, 4 log2_core
+void devsim_math(int op, int n, const double *x, const double *y, double *out) {
+  for (int i = 0; i < n; i++) {
+    switch (op) {
+      case 0: out[i] = fast_exp2(x[i]); break;
+      case 1: out[i] = fast_log2(x[i]); break;
+      case 2: out[i] = fast_pow(x[i], y[i]); break;
+      case 3: out[i] = fast_exp2_core(x[i]); break;
+      case 4: out[i] = fast_log2_core(x[i]); break;
+    }
+  }
+}
 
 int devsim_state_init(const LgarDims *d, const LgarParams *p, LgarState *s, int32_t *status, int dtype) {
 #define X(n) if (d->n_layers == n) return dtype == LGAR_F64 ? init_typed<double, n>(d, p, s, status) : init_typed<float, n>(d, p, s, status);

@@ -196,3 +196,29 @@ def test_tangent_capacity_chain_and_status():
     long = np.concatenate([np.load(os.path.join(GOLDEN, "manyfronts_pulse_84.npz"))["forcing"][:, 0], np.tile([0.02, 0.0], 30)])[:, None]
     gl, _, sl = _engine(g, 1, search_mode=2).tangent({"ksat": d[:, :1]}, long, np.zeros_like(long), w_runoff=np.ones_like(long))
     assert int(sl[0]) & 8
+
+
+def test_columns_outside_the_reference_domain_are_flagged_like_the_oracle():
+    """+-10 % perturbed columns under the synth_1 storm: ~13 % of them make the reference raise ValueError (negative pow
+    base in insert_water's Geff, quirk q3).  Device code (every mode) and oracle must flag exactly the same columns and
+    agree on all the others."""
+    import devsim
+    from lgar_py_amd import workloads as W
+    from oracle import lgar_oracle as O
+    N = 192
+    P = W.perturbed_columns(N, seed=7)
+    sc = W.forcing_scale(N, seed=8)
+    f = W.synth1_forcing()
+    pr = f[:, 0:1] * sc[None, :]
+    pe = np.zeros_like(pr)
+    ro, pc, acc, st = O.run_columns(P["alpha"], P["n"], P["ksat"], P["theta_e"], P["theta_r"], P["thickness"], pr, pe,
+                                    pdm=0.0, dt_h=300.0 / 3600.0)
+    assert 0 < (st != 0).mean() < 0.5
+    for mode in (0, 1, 2):
+        eng = devsim.SimEngine(P["alpha"], P["n"], P["ksat"], P["theta_e"], P["theta_r"], P["thickness"], dt_h=300.0 / 3600.0,
+                               ponded_depth_max=0.0, search_mode=mode)
+        out = eng.forward(pr, pe, series=("runoff",))
+        assert ((st != 0) == (eng.status != 0)).all(), mode
+        ok = st == 0
+        assert np.abs(out["runoff"][:, ok] - ro[:, ok]).max() <= 1e-6 * max(1.0, np.abs(ro).max()), mode
+        assert _rel(eng.totals[:8][:, ok], acc[:8][:, ok], 1e-3).max() <= 1e-6, mode

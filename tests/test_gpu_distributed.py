@@ -49,7 +49,7 @@ def test_two_ranks_sharing_one_gpu_equal_single_rank(tmp_path):
     parts = [np.load(tmp_path / ("two_%d.npz" % r)) for r in range(2)]
     assert int(parts[0]["lo"]) == 0 and int(parts[0]["hi"]) == int(parts[1]["lo"]) == 500 and int(parts[1]["hi"]) == N
     ro = np.concatenate([p["runoff"] for p in parts], axis=1)
-    assert np.array_equal(ro, one["runoff"])
+    assert np.array_equal(ro, one["runoff"], equal_nan=True)
     assert np.array_equal(np.concatenate([p["status"] for p in parts]), one["status"])
     for p in parts:  # every rank holds the all-reduced [T] vector
         assert np.allclose(p["basin"], one["basin"], rtol=1e-12, atol=1e-12)

@@ -17,14 +17,10 @@ VARIANTS = {
     "base": [],
     "dup_geff": ["-DLGAR_DUP_GEFF"],
     "dup_search": ["-DLGAR_DUP_SEARCH"],
-    "dup_psi": ["-DLGAR_DUP_PSI"],
     "dup_mb": ["-DLGAR_DUP_MB"],
-    "skip_nanscan": ["-DLGAR_SKIP_NANSCAN"],
-    "skip_scans": ["-DLGAR_SKIP_SCANS"],
-    "w2": ["-DLGAR_WAVES_F32=2", "-DLGAR_WAVES_F64=1"],
-    "w4_f8": ["-DLGAR_WAVES_F32=4", "-DLGAR_FMAX=8"],
-    "w3_f8": ["-DLGAR_FMAX=8"],
-    "w2_f8": ["-DLGAR_WAVES_F32=2", "-DLGAR_FMAX=8"],
+    "occ3": ["-DLGAR_OCC_F32_SMALL=3"],
+    "occ2": ["-DLGAR_OCC_F32_SMALL=2"],
+    "occ1_f64": ["-DLGAR_OCC_F64_SMALL=1"],
 }
 
 CHILD = r"""
