@@ -112,8 +112,47 @@ def cpu_baseline(target_s=12.0):
             "single_thread": {"value": n1 * T / t1, "cores": 1,
                               "sample": "%d columns x %d steps, 1 thread, %.1f s" % (n1, T, t1)},
             "cpu_model": cpu_model(), "host_cores_visible": avail,
+            "torch_eager_standin": torch_eager_standin(min(3.0, target_s * 0.25)),
             "reference_pytorch_cpu_loop": "10.9 column-timesteps/s on this forcing shape, 1 core (BASELINE.md section 2: observed "
                                           "in the survey container; the Python reference cannot travel to the GPU box)"}
+
+
+def torch_eager_standin(target_s=3.0):
+    """stand-in for "the reference's PyTorch CPU loop" on THIS host.  The reference itself cannot
+    travel to the GPU box; what can be re-established here is the cost of its per-column-timestep torch work: SURVEY.md
+    section 3.4 counted, per column-timestep of the hourly Phillipsburg run, ~840 0-d fp64 torch.pow calls (safe_pow) plus
+    their guards (973 isclose, 2043 isnan, 2043 any) -- 64 % + 25 % of its time sits in those leaf calls.  This replays
+    exactly that op mix (plus 4000 scalar add/mul/sub/div, the remaining arithmetic) on 0-d tensors, one thread, and
+    reports steps/s; the reference measured 12.9 (no_grad) on the survey container's core."""
+    import torch
+    torch.set_num_threads(1)
+    a = torch.tensor(0.37, dtype=torch.float64)
+    b = torch.tensor(1.61, dtype=torch.float64)
+    z = torch.tensor(0.0, dtype=torch.float64)
+
+    def one_step():
+        x = a
+        for _ in range(840):
+            x = torch.pow(a, b)
+        for _ in range(973):
+            torch.isclose(x, z)
+        for _ in range(2043):
+            torch.isnan(x).any()
+        for _ in range(1000):
+            x = (a + b) * a - b / a
+        return x
+
+    with torch.no_grad():
+        one_step()
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < target_s:
+            one_step()
+            n += 1
+        dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "column-timesteps/s", "cores": 1, "kind": "op-mix replay (leaf torch ops only: an UPPER bound "
+            "on the reference loop's throughput on this host; its Python-level bookkeeping is not replayed)",
+            "sample": "%d replays of the reference's per-column-timestep torch op mix (840 pow, 973 isclose, 2043 isnan+any, "
+                      "4000 scalar ops on 0-d fp64 tensors), %.1f s" % (n, dt)}
 
 
 def parse_args(argv=None):

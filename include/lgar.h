@@ -61,6 +61,7 @@ extern "C" {
  * front-capacity chain at the step index held in bits 8..31 */
 #define LGAR_ST_RESUME 128
 #define LGAR_ST_STEP_SHIFT 8
+#define LGAR_NTICKETS 8   /* LgarState.tickets: one counter per kernel of a call's capacity chain (3 used) */
 #define LGAR_NCOUNTERS 4  /* LgarStepOut.counters: [0] wave-level Geff evaluations of the launch; [1..3] reserved */
 
 /* front flag byte: low 7 bits layer number, bit 7 = to_bottom (layers/WettingFront.py:39,49) */
@@ -110,6 +111,11 @@ typedef struct {
   void *scalars;                         /* [LGAR_NSCAL][n_columns] */
   void *totals;                          /* [LGAR_NACC][n_columns]: run totals, what MassBalance accumulates
                                             (physics/MassBalance.py:31-44); rows 8,9 hold the latest value */
+  uint32_t *tickets;                     /* NULL or device uint32[LGAR_NTICKETS]: work counters of the persistent-wave
+                                            schedule (the library zeroes them on the stream at every call).  With tickets the
+                                            forward kernels run as ONE resident wave per wave slot of the chip, each pulling
+                                            64-column blocks until none is left (no partially filled last round); without,
+                                            one workgroup per block. */
 } LgarState;
 
 /* Forcing, each [n_steps][n_columns], cm/h (data/Data.py:32-37). */

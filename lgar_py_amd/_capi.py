@@ -11,6 +11,7 @@ from . import build as _build
 FMAX, LMIN, LMAX, GMAX = 32, 2, 6, 8
 CAP_SMALL, CAP_MID = 8, 16
 NCOUNTERS = 4
+NTICKETS = 8
 ST_RESUME, ST_FAULT_MASK = 128, 0x7F
 NSCAL = 3 + GMAX
 NACC = 10
@@ -39,7 +40,7 @@ class LgarParams(C.Structure):
 
 class LgarState(C.Structure):
     _fields_ = [(nm, C.c_void_p) for nm in ("depth", "theta", "psi", "k", "dzdt", "flags", "n_fronts", "scalars",
-                                            "totals")]
+                                            "totals", "tickets")]
 
 
 class LgarForcing(C.Structure):

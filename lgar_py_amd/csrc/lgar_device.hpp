@@ -119,11 +119,11 @@ template <> struct Tol<float> {
 };
 
 template <typename S> struct LayerK {
-  S alpha, n, m, inv_m, ninv_m, inv_n, ksat, te, tr;
+  S alpha, n, m, inv_m, inv_n, ksat, te, tr;
 };
 
 template <typename S, int NL> struct ColParams {
-  S alpha[NL], n[NL], m[NL], inv_m[NL], ninv_m[NL], inv_n[NL], ksat[NL], te[NL], tr[NL], thick[NL], cum[NL];
+  S alpha[NL], n[NL], m[NL], inv_m[NL], inv_n[NL], ksat[NL], te[NL], tr[NL], thick[NL], cum[NL];
 };
 
 template <typename S, int NL> __device__ __forceinline__ S sel(const S (&a)[NL], int k) {
@@ -144,7 +144,6 @@ template <typename S, int NL> __device__ __forceinline__ LayerK<S> pick(const Co
   l.n = sel<S, NL>(P.n, k);
   l.m = sel<S, NL>(P.m, k);
   l.inv_m = sel<S, NL>(P.inv_m, k);
-  l.ninv_m = sel<S, NL>(P.ninv_m, k);
   l.inv_n = sel<S, NL>(P.inv_n, k);
   l.ksat = sel<S, NL>(P.ksat, k);
   l.te = sel<S, NL>(P.te, k);
@@ -153,7 +152,7 @@ template <typename S, int NL> __device__ __forceinline__ LayerK<S> pick(const Co
 }
 template <typename S, int NL> __device__ __forceinline__ LayerK<S> pick_static(const ColParams<S, NL> &P, int j) {
   LayerK<S> l;
-  l.alpha = P.alpha[j]; l.n = P.n[j]; l.m = P.m[j]; l.inv_m = P.inv_m[j]; l.ninv_m = P.ninv_m[j];
+  l.alpha = P.alpha[j]; l.n = P.n[j]; l.m = P.m[j]; l.inv_m = P.inv_m[j];
   l.inv_n = P.inv_n[j]; l.ksat = P.ksat[j]; l.te = P.te[j]; l.tr = P.tr[j];
   return l;
 }
@@ -192,7 +191,7 @@ template <typename S, bool EX = false> __device__ __forceinline__ S k_from_se(co
 // calc_h_from_se, utils.py:159-174
 template <typename S, bool EX = false> __device__ __forceinline__ S h_from_se(const LayerK<S> &l, S se) {
   using R = real_t<S>;
-  S sp = pwx<EX>(se, l.ninv_m);
+  S sp = pwx<EX>(se, -l.inv_m);
   S base = sp - R(1.0);
   if (ab(val(base)) <= R(1e-8)) base = base + R(1e-12);
   S op = pwx<EX>(base, l.inv_n);
@@ -292,9 +291,15 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <> __device__ __forceinline__ float geff<float>(const LayerK<float> &l, float theta1, float theta2, int nint) {
   const float se_i = se_from_theta(l, theta1);
   const float se_f = se_from_theta(l, theta2);
-  const float h_i = h_from_se(l, se_i);
-  const float h_f = h_from_se(l, se_f);
-  const float dh = (h_f - h_i) / float(nint);
+  // h(Se) of both end points (calc_h_from_se, utils.py:159-174) with one reciprocal of alpha
+  const float inv_alpha = 1.0f / l.alpha;
+  auto head = [&](float se) {
+    float base = pw(se, -l.inv_m) - 1.0f;
+    if (fabsf(base) <= 1e-8f) base = base + 1e-12f;
+    return inv_alpha * pw(base, l.inv_n);
+  };
+  const float h_i = head(se_i), h_f = head(se_f);
+  const float dh = (h_f - h_i) * (1.0f / float(nint));
   const float nm1 = l.n - 1.0f;
   const float hm = -0.5f * l.m;
   const float x0 = l.alpha * h_i, dx = l.alpha * dh, xcut = 0.1f * l.alpha;
@@ -313,39 +318,63 @@ template <> __device__ __forceinline__ float geff<float>(const LayerK<float> &l,
   const int M = nint - 1;       // interior nodes j = 1 .. nint-1
   const int pairs = M >> 1;
   // leading interior nodes with h >= 0.1 for certain: j < (x0 - xcut) / -dx (one node of margin for rounding)
-  const float jf = (x0 - xcut) / -dx - 1.0f;
+#ifndef LGAR_DEVSIM
+  const float jf = (x0 - xcut) * __builtin_amdgcn_rcpf(-dx) - 1.5f;
+#else
+  const float jf = (x0 - xcut) / -dx - 1.5f;
+#endif
   int safe = (jf > 0.0f) ? ((jf < float(M)) ? int(jf) : M) : 0;  // NaN (dx == 0) -> 0
   safe >>= 1;
-  int safe_pairs = 0;  // wave-uniform minimum by bisection on ballots (plain compares + scalar ops)
-  for (int bit = 64; bit; bit >>= 1) {
-    const int cand = safe_pairs + bit;
-    if (cand <= pairs && any_lane(safe < cand) == 0ull) safe_pairs = cand;
+  // wave-uniform minimum: usually every lane is safe for the whole interior (only the end point h_f is near zero)
+  int safe_pairs = pairs;
+  if (any_lane(safe < pairs) != 0ull) {
+    safe_pairs = 0;  // bisection on ballots (plain compares + scalar ops)
+    for (int bit = 64; bit; bit >>= 1) {
+      const int cand = safe_pairs + bit;
+      if (cand <= pairs && any_lane(safe < cand) == 0ull) safe_pairs = cand;
+    }
   }
   const f32x2 dx2 = {dx, dx}, x02 = {x0, x0}, nm12 = {nm1, nm1}, hm2 = {hm, hm};
-  const f32x2 one2 = {1.0f, 1.0f}, two2 = {2.0f, 2.0f};
+  const f32x2 one2 = {1.0f, 1.0f}, two2 = {2.0f, 2.0f}, four2 = {4.0f, 4.0f};
+  const f32x2 step2 = two2 * dx2;
   f32x2 j2 = {1.0f, 2.0f};
-  f32x2 acc = {0.0f, 0.0f};
+  f32x2 acc = {0.0f, 0.0f}, accb = {0.0f, 0.0f};
+  // one node pair: 4 transcendentals + 4 per node-pair ... the packed K_r of two nodes, accumulated by fma
+#define LGAR_GEFF_PAIR(X, ACC)                                                 \
+  {                                                                            \
+    f32x2 lg, P, l1, sr;                                                       \
+    lg.x = lg2((X).x); lg.y = lg2((X).y);                                      \
+    const f32x2 e0 = nm12 * lg;                                                \
+    P.x = ex2(e0.x); P.y = ex2(e0.y);                                          \
+    const f32x2 opa = __builtin_elementwise_fma((X), P, one2);                 \
+    l1.x = lg2(opa.x); l1.y = lg2(opa.y);                                      \
+    const f32x2 e1 = hm2 * l1;                                                 \
+    sr.x = ex2(e1.x); sr.y = ex2(e1.y);                                        \
+    const f32x2 t = __builtin_elementwise_fma(-P, sr * sr, one2);              \
+    (ACC) = __builtin_elementwise_fma(sr, t * t, (ACC));                       \
+  }
   int it = 0;
+  // four nodes per iteration: two independent chains, one node-counter update
+  for (; it + 1 < safe_pairs; it += 2) {
+    const f32x2 xa = __builtin_elementwise_fma(j2, dx2, x02);
+    const f32x2 xb = xa + step2;
+    j2 = j2 + four2;
+    LGAR_GEFF_PAIR(xa, acc)
+    LGAR_GEFF_PAIR(xb, accb)
+  }
   for (; it < safe_pairs; it++) {
     const f32x2 x = __builtin_elementwise_fma(j2, dx2, x02);
     j2 = j2 + two2;
-    f32x2 lg, P, l1, sr;
-    lg.x = lg2(x.x); lg.y = lg2(x.y);
-    const f32x2 e0 = nm12 * lg;
-    P.x = ex2(e0.x); P.y = ex2(e0.y);
-    const f32x2 opa = __builtin_elementwise_fma(x, P, one2);
-    l1.x = lg2(opa.x); l1.y = lg2(opa.y);
-    const f32x2 e1 = hm2 * l1;
-    sr.x = ex2(e1.x); sr.y = ex2(e1.y);
-    const f32x2 t = __builtin_elementwise_fma(-P, sr * sr, one2);
-    acc = acc + sr * (t * t);
+    LGAR_GEFF_PAIR(x, acc)
   }
+#undef LGAR_GEFF_PAIR
   for (; it < pairs; it++) {
     const f32x2 x = __builtin_elementwise_fma(j2, dx2, x02);
     j2 = j2 + two2;
     acc.x += node(x.x);
     acc.y += node(x.y);
   }
+  acc = acc + accb;
   float sum = acc.x + acc.y;
   if (M & 1) sum += node(__builtin_fmaf(float(M), dx, x0));
   const float k0 = node(x0), kn = node(l.alpha * h_f);
@@ -408,14 +437,15 @@ template <typename R> struct Glob {
   long long iter_cap;
 };
 
-// LDS view of one lane's fronts: element i of a field sits at field[i * WAVE]
-template <typename S> struct FrontsView {
-  S *z, *th, *ps, *dz;
-  unsigned char *fl;
-  __device__ __forceinline__ S &Z(int i) const { return z[i * WAVE]; }
-  __device__ __forceinline__ S &TH(int i) const { return th[i * WAVE]; }
-  __device__ __forceinline__ S &PS(int i) const { return ps[i * WAVE]; }
-  __device__ __forceinline__ S &DZ(int i) const { return dz[i * WAVE]; }
+// LDS view of one lane's fronts: element i of field f sits at base[(f * FMAX + i) * WAVE] (one base address per lane; the
+// field offsets are compile-time constants folded into the ds_read / ds_write offsets)
+template <typename S, int FMAX> struct FrontsView {
+  S *base;             // &lds.f[0][0][lane]
+  unsigned char *fl;   // &lds.fl[0][lane]
+  __device__ __forceinline__ S &Z(int i) const { return base[(0 * FMAX + i) * WAVE]; }
+  __device__ __forceinline__ S &TH(int i) const { return base[(1 * FMAX + i) * WAVE]; }
+  __device__ __forceinline__ S &PS(int i) const { return base[(2 * FMAX + i) * WAVE]; }
+  __device__ __forceinline__ S &DZ(int i) const { return base[(3 * FMAX + i) * WAVE]; }
   __device__ __forceinline__ int layer(int i) const { return fl[i * WAVE] & 0x7f; }
   __device__ __forceinline__ bool bottom(int i) const { return (fl[i * WAVE] & LGAR_FLAG_BOTTOM) != 0; }
   __device__ __forceinline__ void set_flag(int i, int layer, bool bottom) const {
@@ -439,7 +469,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
   static constexpr bool EX = (MODE == 0) && (sizeof(R) == 8);
   const ColParams<S, NL> &P;
   const LGAR_KARG Glob<R> *G;  // run-time constants, in the kernarg segment (re-pointed by the kernel's time loop)
-  FrontsView<S> F;
+  FrontsView<S, FMAX> F;
   int nf;
   int status;
   S ponded_water, previous_precip, ending_volume;
@@ -455,11 +485,14 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
   // accumulators drained every forcing step (physics/MassBalance.py:45-53)
   S a_precip, a_pet, a_aet, a_infil, a_runoff, a_perc, a_giuh, a_disch;
 
-  __device__ Column(const ColParams<S, NL> &p, const LGAR_KARG Glob<R> *g, const FrontsView<S> &f) : P(p), G(g), F(f) {}
+  __device__ Column(const ColParams<S, NL> &p, const LGAR_KARG Glob<R> *g, const FrontsView<S, FMAX> &f) : P(p), G(g), F(f) {}
 
   __device__ __forceinline__ S cum_at(int k) const { return sel<S, NL>(P.cum, k); }
   // calc_geff (lgar/green_ampt.py:19-99): trapezoid or closed form, per cfg.data.use_closed_form_G
   __device__ __forceinline__ S capillary_drive(const LayerK<S> &lk, S theta1, S theta2) const {
+#ifdef LGAR_ABL_NOGEFF  // register-pressure experiments (tools/): what the allocator does without the trapezoid
+    return theta1 * theta2 + lk.alpha;
+#endif
     if (wave_geff_calls != nullptr && first_active_lane()) *wave_geff_calls += 1u;
 #ifdef LGAR_DUP_GEFF
     if constexpr (sizeof(S) == sizeof(R)) {
@@ -614,6 +647,9 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
     R delta_mass_prev = delta_mass;
     int count_no_change = 0;
     if (delta_mass <= Tol<R>::mass) return theta_from_h<S, EX>(lk, psi);
+#ifdef LGAR_ABL_NOSEARCH
+    return theta_from_h<S, EX>(lk, psi + new_mass);
+#endif
     if constexpr (MODE != 0) return theta_mass_balance_newton(k, lk, psi, new_mass, prior_mass, dth, dthick, dth_k, dthick_k);
     long long it = 0;
     while (delta_mass > Tol<R>::mass) {
@@ -648,7 +684,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
   __device__ __forceinline__ void check_column_mass(int fdd, S old_mass, S percolation, S aet) {
     S theta_e_k1 = sel<S, NL>(P.te, F.layer(fdd));
     S mass_timestep = (old_mass + percolation) - (aet + R(0.0));
-    if (ab(val(F.TH(fdd)) - val(theta_e_k1)) < Tol<R>::mass) {
+    if (__builtin_expect(ab(val(F.TH(fdd)) - val(theta_e_k1)) < Tol<R>::mass, 0)) {
       S current_mass = mass_balance();
       R err = ab(val(current_mass) - val(mass_timestep));
       bool switched = false;
@@ -794,7 +830,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
         t_psi = psi; t_new = new_mass; t_prior = prior_mass;
         need_search = true;
       }
-      if (need_search) {
+      if (__builtin_expect(need_search, 0)) {
 #ifdef LGAR_DUP_SEARCH
         if constexpr (sizeof(S) == sizeof(R)) {
           const S extra = theta_mass_balance(k, lk, opaque(t_psi), opaque(t_new), opaque(t_prior), dth, dthick, t_dth_k, t_dthick_k);
@@ -983,7 +1019,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
     move_sweep(infiltration, aet, old_mass, fdd);
     S bottom_flux = S(R(0.0));
     // (a per-lane decision: a column's results must not depend on which other columns share its wave)
-    if (front_event_pending()) {
+    if (__builtin_expect(front_event_pending(), 0)) {
       for (int pass = 0; pass < 2; pass++) {
         merge_fronts();
         if (pass == 0) cross_layer_boundary();
@@ -1197,7 +1233,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
         S perc_sub = move_wetting_front(create ? S(R(0.0)) : infiltration_sub, AET_sub, ending_volume_sub, fdd);
         if (!create) a_perc = a_perc + perc_sub;
       }
-      if (create && !saturated) {
+      if (__builtin_expect(create && !saturated, 0)) {
         S dry_depth = calc_dry_depth();
         create_surficial_front(dry_depth, ponded_depth_sub, infiltration_sub);
         a_infil = a_infil + infiltration_sub;

@@ -17,6 +17,7 @@ namespace lgar {
 
 template <typename R> struct KArgs {
   int N, T, F;                                            // columns, forcing steps, rows of the per-front state arrays
+  unsigned *ticket;                                       // null, or the work counter of this launch (persistent waves)
   int chain_first, chain_last;                            // position in the capacity chain (see above)
   const R *alpha, *n, *ksat, *theta_e, *theta_r, *thick;  // [NL][N]
   R *depth, *theta, *psi, *k, *dzdt;                      // [F][N]
@@ -35,10 +36,19 @@ template <typename R> struct KArgs {
   Glob<R> G;
 };
 
-template <typename S, int FMAX> struct WaveLDS {
+// Per-call sums of the accumulators that fit in the wave's LDS budget next to the front table.  They are touched once per
+// forcing step, which makes them the register allocator's first spill victims -- and a spilled read-modify-write is
+// scratch (HBM) write traffic on every step.  The 8-slot fp32 kernel has 10 KB per wave at 4 waves/SIMD: 8.7 KB of
+// fronts + 5 rows of sums; the remaining sums stay in registers.
+template <typename S, int FMAX> struct LdsSums {
+  static constexpr int rows = (sizeof(S) == 4 && FMAX <= LGAR_CAP_SMALL) ? 5 : 8;
+};
+
+template <typename S, int FMAX, int SUMROWS = LdsSums<S, FMAX>::rows> struct WaveLDS {
   S f[4][FMAX][WAVE];
   unsigned char fl[FMAX][WAVE];
   unsigned geff_calls;  // wave-level count of Geff evaluations (measurement)
+  S sums[SUMROWS][WAVE];
 };
 
 #ifndef LGAR_DEVSIM
@@ -81,18 +91,14 @@ __device__ __forceinline__ void load_params(const LGAR_KARG KArgs<R> &a, size_t 
     P.thick[k] = a.thick[k * N + c];
     P.m[k] = R(1.0) - (R(1.0) / P.n[k]);  // calc_m, physics/utils.py:67-69
     P.inv_m[k] = R(1.0) / P.m[k];
-    P.ninv_m[k] = R(-1.0) / P.m[k];
     P.inv_n[k] = R(1.0) / P.n[k];
     P.cum[k] = (k == 0) ? P.thick[0] : P.cum[(k > 0) ? k - 1 : 0] + P.thick[k];  // GlobalParams.py:99-109
   }
 }
 
-template <typename S> __device__ __forceinline__ FrontsView<S> make_view(S *f, unsigned char *fl, int fmax, int lane) {
-  FrontsView<S> F;
-  F.z = f + 0 * fmax * WAVE + lane;
-  F.th = f + 1 * fmax * WAVE + lane;
-  F.ps = f + 2 * fmax * WAVE + lane;
-  F.dz = f + 3 * fmax * WAVE + lane;
+template <typename S, int FMAX> __device__ __forceinline__ FrontsView<S, FMAX> make_view(S *f, unsigned char *fl, int lane) {
+  FrontsView<S, FMAX> F;
+  F.base = f + lane;
   F.fl = fl + lane;
   return F;
 }
@@ -127,7 +133,7 @@ __device__ __forceinline__ void init_lane(const LGAR_KARG KArgs<R> *ap, size_t c
   const LGAR_KARG KArgs<R> &a = *ap;
   ColParams<R, NL> P;
   load_params<R, NL>(a, c, P);
-  Column<R, NL, FMAX, 1> col(P, &ap->G, make_view<R>(&lds.f[0][0][0], &lds.fl[0][0], FMAX, lane));
+  Column<R, NL, FMAX, 1> col(P, &ap->G, make_view<R, FMAX>(&lds.f[0][0][0], &lds.fl[0][0], lane));
   col.init_state();
   const int nf_before = a.nf[c];
   store_state<R, NL, FMAX, 1>(a, c, col, nf_before < 0 ? 0 : nf_before, 0);
@@ -157,7 +163,7 @@ __device__ __forceinline__ void forward_lane(const LGAR_KARG KArgs<R> *ap, size_
   const bool mine = t_begin < a.T;
   ColParams<R, NL> P;
   load_params<R, NL>(a, c, P);
-  Column<R, NL, FMAX, MODE> col(P, &ap->G, make_view<R>(&lds.f[0][0][0], &lds.fl[0][0], FMAX, lane));
+  Column<R, NL, FMAX, MODE> col(P, &ap->G, make_view<R, FMAX>(&lds.f[0][0][0], &lds.fl[0][0], lane));
   // state HBM -> LDS / registers
   const int nf_stored = a.nf[c];
   const int cap = FMAX < a.F ? FMAX : a.F;
@@ -184,9 +190,14 @@ __device__ __forceinline__ void forward_lane(const LGAR_KARG KArgs<R> *ap, size_
   col.wave_geff_calls = &lds.geff_calls;
   if (lane == 0) lds.geff_calls = 0u;
   col.drain();
-  R tot[8];  // accumulators summed over the steps this kernel integrates
+  // accumulators summed over the steps this kernel integrates: the first SR in LDS, the rest in registers
+  constexpr int SR = LdsSums<R, FMAX>::rows;
+  R tot[8];
 #pragma unroll
-  for (int j = 0; j < 8; j++) tot[j] = R(0);
+  for (int j = 0; j < 8; j++) {
+    tot[j] = R(0);
+    if (j < SR) lds.sums[j][lane] = R(0);
+  }
   double wgt = 0.0;
   if (basin_on) wgt = live ? (a.weights ? (double)a.weights[c] : 1.0) : 0.0;
 
@@ -199,22 +210,17 @@ __device__ __forceinline__ void forward_lane(const LGAR_KARG KArgs<R> *ap, size_
     untouched = true;
     if (a.chain_last) col.status |= LGAR_ST_OVERFLOW; else t_handover = t_begin;
   }
-  // software prefetch: the next step's forcing is requested before this step is integrated, so its HBM latency
-  // hides under ~10^4 cycles of VALU work
-  R precip_nx = a.T > 0 ? a.precip[c] : R(0);
-  R pet_nx = a.T > 0 ? a.pet[c] : R(0);
+  // (No software prefetch of the next step's forcing: the two values would have to live in registers across a whole step
+  // -- ~10^4 cycles of VALU work -- and at 128 VGPRs they end up as scratch traffic; the load latency of a step's own
+  // forcing is covered by the other three waves of the SIMD.)
   const int T = a.T;
   for (int t = 0; t < T; t++) {
     ap = launder(ap);
     const LGAR_KARG KArgs<R> &a = *ap;  // (shadows the outer reference on purpose)
     col.G = &ap->G;
     const size_t o = (size_t)t * N + c;
-    const R precip = precip_nx;
-    const R pet = pet_nx;
-    if (t + 1 < T) {
-      precip_nx = a.precip[o + N];
-      pet_nx = a.pet[o + N];
-    }
+    const R precip = a.precip[o];
+    const R pet = a.pet[o];
     bool active = running && t >= t_begin;
     if (active && !a.chain_last && col.nf + a.G.nsub > FMAX) {
       // this step could outgrow the kernel's front capacity: hand the column over, state as of the end of step t-1
@@ -243,7 +249,11 @@ __device__ __forceinline__ void forward_lane(const LGAR_KARG KArgs<R> *ap, size_
     }
     if (active) {
 #pragma unroll
-      for (int j = 0; j < 8; j++) tot[j] = tot[j] + acc[j];  // MassBalance.change_mass, MassBalance.py:31-44
+      for (int j = 0; j < 7; j++) {  // MassBalance.change_mass, MassBalance.py:31-44
+        if (j == 5 && a.G.bottom_mode == 0) continue;  // percolation is identically zero in the reference's mode
+        if (j < SR) lds.sums[j][lane] = lds.sums[j][lane] + acc[j];
+        else tot[j] = tot[j] + acc[j];
+      }  // (discharge [7] is the same sum as giuh_runoff [6]: both gain the same routed runoff, models/dpLGAR.py:293-297)
       col.drain();
     }
   }
@@ -267,6 +277,9 @@ __device__ __forceinline__ void forward_lane(const LGAR_KARG KArgs<R> *ap, size_
     return;
   }
   store_state<R, NL, FMAX, MODE>(z, c, col, nf_before, word);
+#pragma unroll
+  for (int j = 0; j < SR && j < 7; j++) tot[j] = lds.sums[j][lane];
+  tot[7] = tot[6];
 #pragma unroll
   for (int j = 0; j < 8; j++) z.totals[j * N + c] = z.totals[j * N + c] + tot[j];  // MassBalance's run totals
   z.totals[8 * N + c] = col.ponded_water;

@@ -24,7 +24,6 @@ template <typename R> __global__ void lgar_leaf_kernel(LeafArgs<R> a) {
   l.n = a.nn[i];
   l.m = R(1.0) - (R(1.0) / l.n);
   l.inv_m = R(1.0) / l.m;
-  l.ninv_m = R(-1.0) / l.m;
   l.inv_n = R(1.0) / l.n;
   l.ksat = a.ksat[i];
   l.te = a.te[i];

@@ -46,12 +46,27 @@ template <typename R, int NL, int CAP, int MODE>
 __global__ __launch_bounds__(WAVE, (Occupancy<R, CAP>::waves)) void lgar_forward_kernel(KArgs<R> a) {
   __shared__ WaveLDS<R, CAP> lds;
   const int lane = threadIdx.x;
-  const size_t N = (size_t)a.N;
-  const size_t c0 = (size_t)blockIdx.x * WAVE + lane;
-  const bool live = c0 < N;
   // the argument block is read in place (kernarg segment), see LGAR_KARG in lgar_device.hpp
-  forward_lane<R, NL, CAP, MODE>((const LGAR_KARG KArgs<R> *)__builtin_amdgcn_kernarg_segment_ptr(), live ? c0 : N - 1, live,
-                                 lane, lds);
+  const LGAR_KARG KArgs<R> *ap = (const LGAR_KARG KArgs<R> *)__builtin_amdgcn_kernarg_segment_ptr();
+  const size_t N = (size_t)ap->N;
+  unsigned *ticket = ap->ticket;
+  // With a ticket counter: persistent waves.  The grid is one wave per wave slot of the chip; each pulls 64-column blocks
+  // from the counter until none is left, so no round of the grid is partially filled whatever the column count.
+  // Without: one workgroup per block.
+  const unsigned nblocks = (unsigned)((N + WAVE - 1) / WAVE);
+  for (bool first = true;; first = false) {
+    unsigned blk = blockIdx.x;
+    if (ticket != nullptr) {
+      if (lane == 0) blk = atomicAdd(ticket, 1u);
+      blk = __builtin_amdgcn_readfirstlane(blk);
+      if (blk >= nblocks) break;
+    } else if (!first) {
+      break;
+    }
+    const size_t c0 = (size_t)blk * WAVE + lane;
+    const bool live = c0 < N;
+    forward_lane<R, NL, CAP, MODE>(ap, live ? c0 : N - 1, live, lane, lds);
+  }
 }
 
 template <typename R>
@@ -61,6 +76,7 @@ static KArgs<R> make_args(const LgarDims *d, const LgarParams *p, LgarState *s, 
   a.N = d->n_columns;
   a.T = d->n_steps;
   a.F = front_slots(d);
+  a.ticket = nullptr;
   a.chain_first = a.chain_last = 1;
   a.alpha = (const R *)p->alpha; a.n = (const R *)p->n; a.ksat = (const R *)p->ksat;
   a.theta_e = (const R *)p->theta_e; a.theta_r = (const R *)p->theta_r; a.thick = (const R *)p->thickness;
@@ -90,6 +106,29 @@ static int init_typed(const LgarDims *dims, const LgarParams *params, LgarState 
   return launch_status();
 }
 
+// wave slots of the chip for a kernel compiled for `waves` waves per SIMD
+static unsigned wave_slots(int waves) {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    cus = n;
+  }
+  return (unsigned)cus * 4u * (unsigned)waves;
+}
+
+template <typename R, int NL, int CAP, int MODE>
+static void launch_forward_kernel(KArgs<R> &a, unsigned nblocks, unsigned *ticket, hipStream_t st) {
+  a.ticket = ticket;
+  unsigned grid = nblocks;
+  if (ticket != nullptr) {
+    const unsigned slots = wave_slots(Occupancy<R, CAP>::waves);
+    grid = nblocks < slots ? nblocks : slots;
+  }
+  hipLaunchKernelGGL((lgar_forward_kernel<R, NL, CAP, MODE>), dim3(grid), dim3(WAVE), 0, st, a);
+}
+
 // The front-capacity chain of one lgar_forward call (see lgar_forward_body.hpp).
 template <typename R, int NL>
 static int forward_typed(const LgarDims *dims, const LgarParams *params, LgarState *state, const LgarForcing *forcing,
@@ -97,9 +136,11 @@ static int forward_typed(const LgarDims *dims, const LgarParams *params, LgarSta
   const unsigned grid = (unsigned)((dims->n_columns + WAVE - 1) / WAVE);
   KArgs<R> a = make_args<R>(dims, params, state, forcing, out, status);
   const int slots = a.F;
+  unsigned *tickets = state->tickets;
+  if (tickets != nullptr && hipMemsetAsync(tickets, 0, LGAR_NTICKETS * sizeof(unsigned), st) != hipSuccess) return LGAR_E_LAUNCH;
   if (dims->search_mode == 0) {
     // the reference's literal searches: verification mode, one kernel at the full capacity
-    hipLaunchKernelGGL((lgar_forward_kernel<R, NL, LGAR_FMAX, 0>), dim3(grid), dim3(WAVE), 0, st, a);
+    launch_forward_kernel<R, NL, LGAR_FMAX, 0>(a, grid, tickets, st);
     return launch_status();
   }
   // smallest capacity that leaves room for a forcing step (one front per layer + one new front per sub-step + slack);
@@ -113,16 +154,11 @@ static int forward_typed(const LgarDims *dims, const LgarParams *params, LgarSta
   for (int i = 0; i < nc; i++) {
     a.chain_first = (i == 0);
     a.chain_last = (i == nc - 1);
+    unsigned *tk = tickets ? tickets + i : nullptr;
     switch (caps[i]) {
-      case LGAR_CAP_SMALL:
-        hipLaunchKernelGGL((lgar_forward_kernel<R, NL, LGAR_CAP_SMALL, 1>), dim3(grid), dim3(WAVE), 0, st, a);
-        break;
-      case LGAR_CAP_MID:
-        hipLaunchKernelGGL((lgar_forward_kernel<R, NL, LGAR_CAP_MID, 1>), dim3(grid), dim3(WAVE), 0, st, a);
-        break;
-      default:
-        hipLaunchKernelGGL((lgar_forward_kernel<R, NL, LGAR_FMAX, 1>), dim3(grid), dim3(WAVE), 0, st, a);
-        break;
+      case LGAR_CAP_SMALL: launch_forward_kernel<R, NL, LGAR_CAP_SMALL, 1>(a, grid, tk, st); break;
+      case LGAR_CAP_MID: launch_forward_kernel<R, NL, LGAR_CAP_MID, 1>(a, grid, tk, st); break;
+      default: launch_forward_kernel<R, NL, LGAR_FMAX, 1>(a, grid, tk, st); break;
     }
     const int rc = launch_status();
     if (rc) return rc;

@@ -29,7 +29,7 @@ template <typename R> struct TArgs {
 };
 
 template <typename R, int NL, int FMAX, int MODE>
-__device__ __forceinline__ void tangent_lane(const LGAR_KARG TArgs<R> *ap, size_t c, int lane, WaveLDS<Dual<R>, FMAX> &lds) {
+__device__ __forceinline__ void tangent_lane(const LGAR_KARG TArgs<R> *ap, size_t c, int lane, WaveLDS<Dual<R>, FMAX, 1> &lds) {
   using S = Dual<R>;
   const LGAR_KARG TArgs<R> &a = *ap;
   const size_t N = (size_t)a.N;
@@ -50,11 +50,10 @@ __device__ __forceinline__ void tangent_lane(const LGAR_KARG TArgs<R> *ap, size_
     P.thick[k] = S(a.thick[o]);
     P.m[k] = R(1.0) - (R(1.0) / P.n[k]);
     P.inv_m[k] = R(1.0) / P.m[k];
-    P.ninv_m[k] = R(-1.0) / P.m[k];
     P.inv_n[k] = R(1.0) / P.n[k];
     P.cum[k] = (k == 0) ? P.thick[0] : P.cum[(k > 0) ? k - 1 : 0] + P.thick[k];
   }
-  Column<S, NL, FMAX, MODE> col(P, &ap->G, make_view<S>(&lds.f[0][0][0], &lds.fl[0][0], FMAX, lane));
+  Column<S, NL, FMAX, MODE> col(P, &ap->G, make_view<S, FMAX>(&lds.f[0][0][0], &lds.fl[0][0], lane));
   col.init_state();
   R grad = R(0);
   bool handed_over = false;

@@ -13,7 +13,7 @@
 namespace lgar {
 
 template <typename R, int NL, int CAP, int MODE> __global__ __launch_bounds__(WAVE) void lgar_tangent_kernel(TArgs<R> a) {
-  __shared__ WaveLDS<Dual<R>, CAP> lds;
+  __shared__ WaveLDS<Dual<R>, CAP, 1> lds;
   const int lane = threadIdx.x;
   const size_t c = (size_t)blockIdx.x * WAVE + lane;
   if (c >= (size_t)a.N) return;

@@ -100,11 +100,13 @@ class LgarEngine:
         self.totals = z(NACC, N)
         self.status = z(N, dt=torch.int32)
         self.counters = z(_capi.NCOUNTERS, dt=torch.int64)
+        self.tickets = z(_capi.NTICKETS, dt=torch.int32)  # work counters of the persistent-wave schedule
 
         self._params = _capi.LgarParams(*[t.data_ptr() for t in (self.alpha, self.n, self.ksat, self.theta_e,
                                                                  self.theta_r, self.thickness)])
         self._state = _capi.LgarState(*[t.data_ptr() for t in (self.depth, self.theta, self.psi, self.k, self.dzdt,
-                                                               self.flags, self.n_fronts, self.scalars, self.totals)])
+                                                               self.flags, self.n_fronts, self.scalars, self.totals,
+                                                               self.tickets)])
         self.reset()
 
     # ------------------------------------------------------------------------------------------

@@ -33,7 +33,7 @@ class LgarParams(C.Structure):
 
 
 class LgarState(C.Structure):
-    _fields_ = [(nm, C.c_void_p) for nm in ("depth", "theta", "psi", "k", "dzdt", "flags", "n_fronts", "scalars", "totals")]
+    _fields_ = [(nm, C.c_void_p) for nm in ("depth", "theta", "psi", "k", "dzdt", "flags", "n_fronts", "scalars", "totals", "tickets")]
 
 
 class LgarForcing(C.Structure):
@@ -117,7 +117,7 @@ class SimEngine:
         ptr = lambda a: a.ctypes.data_as(C.c_void_p)
         self._params = LgarParams(*[ptr(t) for t in (self.alpha, self.n, self.ksat, self.theta_e, self.theta_r, self.thickness)])
         self._state = LgarState(*[ptr(t) for t in (self.depth, self.theta, self.psi, self.k, self.dzdt, self.flags,
-                                                   self.n_fronts, self.scalars, self.totals)])
+                                                   self.n_fronts, self.scalars, self.totals)] + [None])
         self.reset()
 
     def reset(self):

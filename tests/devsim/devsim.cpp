@@ -39,6 +39,7 @@ KArgs<R> make_args(const LgarDims *d, const LgarParams *p, LgarState *s, const L
   KArgs<R> a;
   a.N = d->n_columns; a.T = d->n_steps; a.F = d->front_slots > 0 ? d->front_slots : LGAR_FMAX;
   a.chain_first = a.chain_last = 1;
+  a.ticket = nullptr;
   a.alpha = (const R *)p->alpha; a.n = (const R *)p->n; a.ksat = (const R *)p->ksat;
   a.theta_e = (const R *)p->theta_e; a.theta_r = (const R *)p->theta_r; a.thick = (const R *)p->thickness;
   a.depth = (R *)s->depth; a.theta = (R *)s->theta; a.psi = (R *)s->psi; a.k = (R *)s->k; a.dzdt = (R *)s->dzdt;
@@ -85,7 +86,7 @@ template <typename R, int NL> int init_typed(const LgarDims *d, const LgarParams
 }
 
 template <typename R, int NL, int CAP, int MODE> void run_tangent(const TArgs<R> &a) {
-  std::vector<WaveLDS<Dual<R>, CAP>> lds(1);
+  std::vector<WaveLDS<Dual<R>, CAP, 1>> lds(1);
   for (int c = 0; c < a.N; c++) tangent_lane<R, NL, CAP, MODE>(&a, (size_t)c, 0, lds[0]);
 }
 

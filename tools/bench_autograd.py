@@ -27,7 +27,8 @@ for rep in range(2):
     torch.cuda.synchronize(); t1 = time.perf_counter()
     loss.backward()
     torch.cuda.synchronize(); t2 = time.perf_counter()
-    res = dict(columns=N, T=T, dtype=str(dtype), valid_fraction=float(ok.double().mean()), loss=float(loss),
+    res = dict(columns=N, T=T, dtype=str(dtype), valid_fraction=float(ok.double().mean()), loss=float(loss.detach()),
+               tangent_faulted_fraction=float((st[1] != 0).double().mean()),
                fwd_ms=1e3 * (t1 - t0), bwd_ms=1e3 * (t2 - t1), fwd_col_steps_per_s=N * T / (t1 - t0),
                fwd_bwd_col_steps_per_s=N * T / (t2 - t0))
 print(json.dumps(res))
