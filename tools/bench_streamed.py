@@ -21,4 +21,5 @@ for rep in range(2):
 st = eng.status.cpu().numpy()
 print(json.dumps(dict(columns=N, T=T, dtype=str(dtype), seconds=dt, col_steps_per_s=N * T / dt, faulted_fraction=float((st != 0).mean()),
                       aet_total_mean_cm=float(eng.totals[2].double().mean()), max_fronts=int(eng.n_fronts.max()))))
-print({b: int(((st & b) != 0).sum()) for b in (1, 2, 4, 8, 16, 32, 64)}, "n_fronts hist", np.bincount(eng.n_fronts.cpu().numpy(), minlength=13).tolist())
+print(json.dumps({"status_bit_counts": {str(b): int(((st & b) != 0).sum()) for b in (1, 2, 4, 8, 16, 32, 64)}, "overflow_columns": int(((st & 8) != 0).sum()),
+                  "n_fronts_hist": np.bincount(eng.n_fronts.cpu().numpy(), minlength=33).tolist()}))

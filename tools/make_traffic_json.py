@@ -23,8 +23,7 @@ for f in glob.glob(prof + "/" + prefix + "stats/*kernel_stats.csv"):
     for r in csv.DictReader(open(f)):
         if kern in r["Name"]:
             ms = float(r["AverageNs"]) * 1e-6
-waves = med.get("SQ_WAVES", cols / 64)
-steps = waves * T
+steps = (cols / 64) * T  # wave-steps: 64-column blocks x forcing steps (the persistent grid launches fewer waves than blocks)
 valu = {
     "bound": "valu-issue", "kernel": kern, "kernel_ms_rocprof": ms,
     "SQ_INSTS_VALU": med.get("SQ_INSTS_VALU"), "SQ_INSTS_VALU_TRANS_F32": med.get("SQ_INSTS_VALU_TRANS_F32"),
