@@ -357,7 +357,10 @@ def main():
         units = N * world * T * args.steps
         b_alg = alg_bytes_per_col_step(elem, T)
         achieved = b_alg * N * T / (kern_ms * 1e-3) / 1e9
-        kname = "lgar_forward_kernel<%s,3,%d>" % ("float" if elem == 4 else "double", lg._capi.FMAX)
+        # the kernel that carries the work: the 8-slot member of the front-capacity chain for jobs above 1024 waves
+        # (include/lgar.h), named as rocprofv3 prints it
+        kname = "lgar_forward_kernel<%s, 3, %d, 1>" % ("float" if elem == 4 else "double",
+                                                        lg._capi.CAP_SMALL if N > 65536 else lg._capi.FMAX)
         line = {
             "metric": "column-timesteps/sec", "value": units / elapsed, "unit": "column-timesteps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(args.steps, 1),
