@@ -72,6 +72,23 @@ template <bool EX> __device__ __forceinline__ double pwx(double x, double y) {
   return pw(x, y);
 }
 template <bool EX> __device__ __forceinline__ float pwx(float x, float y) { return pw(x, y); }
+
+// Arithmetic policy of the leaf functions and the column physics (template parameter POL):
+//   0  lean pow (lgar_math.hpp), IEEE division                        -- fp64 fast mode, dual numbers
+//   1  library pow, IEEE division                                     -- verification mode in double precision
+//   2  v_log/v_exp pow, division as a * v_rcp_f32(b) (<= 1.5 ulp)     -- fp32 fast mode: the correctly rounded fp32 divide
+//      is ~10 instructions, the path takes ~20 of them per column-step.  Se = (theta - theta_r)/(theta_e - theta_r) keeps
+//      the IEEE divide in every policy: Se must be exactly 1 at saturation (x/x == 1), or the pow bases go negative.
+#ifndef LGAR_DEVSIM
+__device__ __forceinline__ float rcp32(float b) { return __builtin_amdgcn_rcpf(b); }
+#else
+__device__ __forceinline__ float rcp32(float b) { return 1.0f / b; }
+#endif
+template <int POL> __device__ __forceinline__ float dv(float a, float b) {
+  if constexpr (POL == 2) return a * rcp32(b);
+  return a / b;
+}
+template <int POL> __device__ __forceinline__ double dv(double a, double b) { return a / b; }
 #ifdef LGAR_F64_LIBM
 __device__ __forceinline__ double lg2(double x) { return log2(x); }
 __device__ __forceinline__ double ex2(double x) { return exp2(x); }
@@ -161,26 +178,29 @@ template <typename S, int NL> __device__ __forceinline__ LayerK<S> pick_static(c
 // van Genuchten leaf functions (models/physics/utils.py)
 // ---------------------------------------------------------------------------------------------
 // calc_theta_from_h, utils.py:35-51
-template <typename S, bool EX = false> __device__ __forceinline__ S theta_from_h(const LayerK<S> &l, S h) {
+template <typename S, int POL = 0> __device__ __forceinline__ S theta_from_h(const LayerK<S> &l, S h) {
   using R = real_t<S>;
+  constexpr bool EX = POL == 1;
   S ap = pwx<EX>(l.alpha * h, l.n);
   S op = pwx<EX>(R(1.0) + ap, l.m);
-  return (R(1.0) / op * (l.te - l.tr)) + l.tr;
+  return (dv<POL>(S(R(1.0)), op) * (l.te - l.tr)) + l.tr;
 }
 // calc_se_from_theta, utils.py:102-112
 template <typename S> __device__ __forceinline__ S se_from_theta(const LayerK<S> &l, S theta) {
   return (theta - l.tr) / (l.te - l.tr);
 }
 // calc_se_from_h, utils.py:115-131 (exactly 1 for |h| < 0.1)
-template <typename S, bool EX = false> __device__ __forceinline__ S se_from_h(const LayerK<S> &l, S h) {
+template <typename S, int POL = 0> __device__ __forceinline__ S se_from_h(const LayerK<S> &l, S h) {
   using R = real_t<S>;
+  constexpr bool EX = POL == 1;
   if (ab(val(h)) < R(1.0e-01)) return S(R(1.0));
   S is = pwx<EX>(l.alpha * h, l.n);
-  return R(1.0) / pwx<EX>(R(1.0) + is, l.m);
+  return dv<POL>(S(R(1.0)), pwx<EX>(R(1.0) + is, l.m));
 }
 // calc_k_from_se, utils.py:134-156; torch.isclose(base, 0, rtol=1e-12) => |base| <= 1e-8 (default atol)
-template <typename S, bool EX = false> __device__ __forceinline__ S k_from_se(const LayerK<S> &l, S se) {
+template <typename S, int POL = 0> __device__ __forceinline__ S k_from_se(const LayerK<S> &l, S se) {
   using R = real_t<S>;
+  constexpr bool EX = POL == 1;
   S sp = pwx<EX>(se, l.inv_m);
   S base = R(1.0) - sp;
   if (ab(val(base)) <= R(1e-8)) base = base + R(1e-12);
@@ -189,32 +209,33 @@ template <typename S, bool EX = false> __device__ __forceinline__ S k_from_se(co
   return l.ksat * sq(se) * (t * t);
 }
 // calc_h_from_se, utils.py:159-174
-template <typename S, bool EX = false> __device__ __forceinline__ S h_from_se(const LayerK<S> &l, S se) {
+template <typename S, int POL = 0> __device__ __forceinline__ S h_from_se(const LayerK<S> &l, S se) {
   using R = real_t<S>;
+  constexpr bool EX = POL == 1;
   S sp = pwx<EX>(se, -l.inv_m);
   S base = sp - R(1.0);
   if (ab(val(base)) <= R(1e-8)) base = base + R(1e-12);
   S op = pwx<EX>(base, l.inv_n);
-  return R(1.0) / l.alpha * op;
+  return dv<POL>(S(R(1.0)), l.alpha) * op;
 }
 // calc_geff, models/physics/lgar/green_ampt.py:45-84: nint-interval trapezoid of K(h) dh / Ksat.
 // The discretisation error is part of the answer: same nodes (h accumulated by repeated += dh).
-template <typename S, bool EX = false> __device__ __forceinline__ S geff_literal(const LayerK<S> &l, S theta1, S theta2, int nint) {
+template <typename S, int POL = 0> __device__ __forceinline__ S geff_literal(const LayerK<S> &l, S theta1, S theta2, int nint) {
   using R = real_t<S>;
   S se_i = se_from_theta(l, theta1);
   S se_f = se_from_theta(l, theta2);
-  S h_i = h_from_se<S, EX>(l, se_i);
-  S h_f = h_from_se<S, EX>(l, se_f);
+  S h_i = h_from_se<S, POL>(l, se_i);
+  S h_f = h_from_se<S, POL>(l, se_f);
   S dh = (h_f - h_i) / R(nint);
   S g = S(R(0.0));
-  S k1 = k_from_se<S, EX>(l, se_i);
+  S k1 = k_from_se<S, POL>(l, se_i);
   S h2 = h_i + dh;
   S hdh = dh / R(2.0);
   for (int i = 0; i < nint; i++) {
     // rounding in the repeated h2 += dh can carry the last nodes past 0 (by ~1e-10 in fp64): a negative head is
     // saturation (Se = 1, the |h| < 0.1 rule), never pow of a negative base
-    S se2 = (val(h2) < R(0.0)) ? S(R(1.0)) : se_from_h<S, EX>(l, h2);
-    S k2 = k_from_se<S, EX>(l, se2);
+    S se2 = (val(h2) < R(0.0)) ? S(R(1.0)) : se_from_h<S, POL>(l, h2);
+    S k2 = k_from_se<S, POL>(l, se2);
     g = g + ((k1 + k2) * hdh);
     k1 = k2;
     h2 = h2 + dh;
@@ -223,7 +244,7 @@ template <typename S, bool EX = false> __device__ __forceinline__ S geff_literal
 }
 // the trapezoid the kernels use by default: specialised below for float / double (and the dual numbers, lgar_dual.hpp)
 template <typename S> __device__ __forceinline__ S geff(const LayerK<S> &l, S theta1, S theta2, int nint) {
-  return geff_literal<S, false>(l, theta1, theta2, nint);
+  return geff_literal<S, 0>(l, theta1, theta2, nint);
 }
 
 // fp32 Geff: the same 121 nodes with Se(h) -> K(Se) fused per node.  With a = (alpha h)^n:
@@ -394,8 +415,9 @@ template <> __device__ __forceinline__ double geff<double>(const LayerK<double> 
 // calc_geff with use_closed_form_G (lgar/green_ampt.py:85-98): Brooks-Corey estimate from the van Genuchten parameters
 // (calc_bc_lambda / calc_bc_psib, physics/utils.py:54-64, 84-99).  Operator precedence as written in the reference:
 // geff = h_c * Se_i^e - Se_f^e / (1 - Se_f^e), with Se_f from theta_1 and Se_i from theta_2; inf/nan -> h_c.
-template <typename S, bool EX = false> __device__ __forceinline__ S geff_closed(const LayerK<S> &l, S theta1, S theta2) {
+template <typename S, int POL = 0> __device__ __forceinline__ S geff_closed(const LayerK<S> &l, S theta1, S theta2) {
   using R = real_t<S>;
+  constexpr bool EX = POL == 1;
   const S p = R(1.0) + (R(2.0) / l.m);
   const S lambda = R(2.0) / (p - R(3.0));
   const S psib = (p + R(3.0)) * (R(147.8) + R(8.1) * p + R(0.092) * p * p) /
@@ -412,13 +434,13 @@ template <typename S, bool EX = false> __device__ __forceinline__ S geff_closed(
 }
 
 // calc_aet, models/physics/lgar/aet.py:17-51 (0.75: GlobalParams.py:75; clamp upper bound = PET rate)
-template <typename S, bool EX = false> __device__ __forceinline__ S aet_fn(const LayerK<S> &l, S pet, real_t<S> dt_h, S psi, real_t<S> wp_psi) {
+template <typename S, int POL = 0> __device__ __forceinline__ S aet_fn(const LayerK<S> &l, S pet, real_t<S> dt_h, S psi, real_t<S> wp_psi) {
   using R = real_t<S>;
   S theta_fc = (l.te - l.tr) * R(0.75) + l.tr;
-  S wp_head_theta = theta_from_h<S, EX>(l, S(wp_psi));
+  S wp_head_theta = theta_from_h<S, POL>(l, S(wp_psi));
   S theta_wp = (theta_fc - wp_head_theta) * R(0.5) + wp_head_theta;
   S se = se_from_theta(l, theta_wp);
-  S psi_wp = h_from_se<S, EX>(l, se);
+  S psi_wp = h_from_se<S, POL>(l, se);
   S r = psi / psi_wp;
   S h_ratio = R(1.0) + r * r * r;
   S a = pet * (R(1.0) / h_ratio) * dt_h;
@@ -465,8 +487,9 @@ template <typename S, int FMAX> struct FrontsView {
 // passes that are provably no-ops between events are skipped (see forward()).
 template <typename S, int NL, int FMAX, int MODE> struct Column {
   using R = real_t<S>;
-  // verification mode in double precision: every pow is the library's correctly rounded one (the reference's torch.pow)
-  static constexpr bool EX = (MODE == 0) && (sizeof(R) == 8);
+  // arithmetic policy (see dv / pwx): verification mode in double precision uses the library pow (the reference's
+  // torch.pow); the plain-float fast mode divides by reciprocal; everything else is lean pow + IEEE division
+  static constexpr int POL = ((MODE == 0) && (sizeof(R) == 8)) ? 1 : (((MODE != 0) && (sizeof(S) == 4)) ? 2 : 0);
   const ColParams<S, NL> &P;
   const LGAR_KARG Glob<R> *G;  // run-time constants, in the kernarg segment (re-pointed by the kernel's time loop)
   FrontsView<S, FMAX> F;
@@ -502,9 +525,9 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
 #endif
     if constexpr (MODE == 0 && sizeof(R) == 8) {
       // verification mode: the reference's trapezoid operation by operation (4 pow + sqrt per node, running h)
-      return G->closed_form ? geff_closed<S, EX>(lk, theta1, theta2) : geff_literal<S, EX>(lk, theta1, theta2, G->nint);
+      return G->closed_form ? geff_closed<S, POL>(lk, theta1, theta2) : geff_literal<S, POL>(lk, theta1, theta2, G->nint);
     }
-    return G->closed_form ? geff_closed<S, EX>(lk, theta1, theta2) : geff(lk, theta1, theta2, G->nint);
+    return G->closed_form ? geff_closed<S, POL>(lk, theta1, theta2) : geff(lk, theta1, theta2, G->nint);
   }
   __device__ __forceinline__ S cum_prev(int k) const {  // cum[k-1], 0 for k == 0
     S r = S(R(0.0));
@@ -571,21 +594,22 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
     R ap = pw(alpha * psi, n);
     R one_ap = R(1.0) + ap;
     R op = pw(one_ap, m);
-    R span = R(1.0) / op * (te - tr);
+    R span = dv<POL>(R(1.0), op) * (te - tr);
     th = span + tr;
-    dth = (psi > R(0.0)) ? -(span * m * n * ap) / (psi * one_ap) : R(0.0);
+    dth = (psi > R(0.0)) ? dv<POL>(-(span * m * n * ap), psi * one_ap) : R(0.0);
   }
 
   // search_mode 1: the same root -- psi with |sum_j thick_j (theta_j(psi) - dtheta_j) - prior_mass| <= tolerance --
   // found by a bracketed Newton iteration (5-8 mass evaluations) instead of the reference's fixed-step decimal
   // search (58-82 on average, Layer.py:275-317).  theta differs from the literal search by <= tolerance / thickness.
   // Gradient semantics (dual numbers): psi_final = psi_init + constant, as in the reference (Layer.py:277-288).
-  __device__ __forceinline__ S theta_mass_balance_newton(int k, const LayerK<S> &lk, S psi0, S new_mass, S prior_mass,
+  template <int K>
+  __device__ __forceinline__ S theta_mass_balance_newton(const LayerK<S> &lk, S psi0, S new_mass, S prior_mass,
                                                          const S (&dth)[NL], const S (&dthick)[NL], S dth_k, S dthick_k) {
     const R prior = val(prior_mass);
     R psi = val(psi0);
     R f = val(new_mass) - prior;
-    if (ab(f) <= Tol<R>::mass) return theta_from_h<S, EX>(lk, psi0);
+    if (ab(f) <= Tol<R>::mass) return theta_from_h<S, POL>(lk, psi0);
     R M = R(0.0), dM = R(0.0);
     auto eval = [&](R x) {
       R thk, dthk;
@@ -593,13 +617,12 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
       M = val(dthick_k) * (thk - val(dth_k));
       dM = val(dthick_k) * dthk;
 #pragma unroll
-      for (int j = 0; j < NL - 1; j++)
-        if (j < k) {
-          R tj, dj;
-          theta_slope(val(P.alpha[j]), val(P.n[j]), val(P.m[j]), val(P.te[j]), val(P.tr[j]), x, tj, dj);
-          M += val(dthick[j]) * (tj - val(dth[j]));
-          dM += val(dthick[j]) * dj;
-        }
+      for (int j = 0; j < K; j++) {
+        R tj, dj;
+        theta_slope(val(P.alpha[j]), val(P.n[j]), val(P.m[j]), val(P.te[j]), val(P.tr[j]), x, tj, dj);
+        M += val(dthick[j]) * (tj - val(dth[j]));
+        dM += val(dthick[j]) * dj;
+      }
     };
     R lo = R(0.0), hi = R(-1.0);  // bracket f(lo) > 0 > f(hi); hi < 0: not found yet
     bool lo_ok = false;
@@ -616,13 +639,12 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
           // is the target reachable at all?  mass at psi = 0 (saturation) needs no pow
           R M0 = val(dthick_k) * (((val(lk.te) - val(lk.tr)) + val(lk.tr)) - val(dth_k));
 #pragma unroll
-          for (int j = 0; j < NL - 1; j++)
-            if (j < k) M0 += val(dthick[j]) * (((val(P.te[j]) - val(P.tr[j])) + val(P.tr[j])) - val(dth[j]));
+          for (int j = 0; j < K; j++) M0 += val(dthick[j]) * (((val(P.te[j]) - val(P.tr[j])) + val(P.tr[j])) - val(dth[j]));
           if (M0 - prior <= Tol<R>::mass) { psi = R(0.0); break; }  // saturated: the reference walks psi -> 0 (Layer.py:287-316)
           lo_ok = true;
         }
       }
-      R pn = (dM < R(0.0)) ? psi - f / dM : R(-1.0);
+      R pn = (dM < R(0.0)) ? psi - dv<POL>(f, dM) : R(-1.0);
       const bool inside = (pn > lo) && (hi < R(0.0) || pn < hi);
       if (!inside) pn = (hi >= R(0.0)) ? R(0.5) * (lo + hi) : psi * R(2.0) + R(1.0);
       if (pn == psi) break;  // step below resolution
@@ -632,12 +654,13 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
       if (it == 63) status |= LGAR_ST_ITERCAP;
     }
     const S psi_final = psi0 + (psi - val(psi0));
-    return theta_from_h<S, EX>(lk, psi_final);
+    return theta_from_h<S, POL>(lk, psi_final);
   }
 
   // theta_mass_balance, Layer.py:242-318 (+ recalculate_mass :211-240).  k = the front's layer;
-  // dth/dthick hold the entries of the layers above (j < k), dth_k/dthick_k the front's own.
-  __device__ __forceinline__ S theta_mass_balance(int k, const LayerK<S> &lk, S psi, S new_mass, S prior_mass, const S (&dth)[NL],
+  // dth/dthick hold the entries of the layers above (j < K), dth_k/dthick_k the front's own.
+  template <int K>
+  __device__ __forceinline__ S theta_mass_balance(const LayerK<S> &lk, S psi, S new_mass, S prior_mass, const S (&dth)[NL],
                                   const S (&dthick)[NL], S dth_k, S dthick_k) {
     R delta_mass = ab(val(new_mass) - val(prior_mass));
     bool switched = false;
@@ -646,11 +669,11 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
     S psi_prev = psi;  // a tensor in the reference: psi_prev * 0.1 below carries its gradient
     R delta_mass_prev = delta_mass;
     int count_no_change = 0;
-    if (delta_mass <= Tol<R>::mass) return theta_from_h<S, EX>(lk, psi);
+    if (delta_mass <= Tol<R>::mass) return theta_from_h<S, POL>(lk, psi);
 #ifdef LGAR_ABL_NOSEARCH
-    return theta_from_h<S, EX>(lk, psi + new_mass);
+    return theta_from_h<S, POL>(lk, psi + new_mass);
 #endif
-    if constexpr (MODE != 0) return theta_mass_balance_newton(k, lk, psi, new_mass, prior_mass, dth, dthick, dth_k, dthick_k);
+    if constexpr (MODE != 0) return theta_mass_balance_newton<K>(lk, psi, new_mass, prior_mass, dth, dthick, dth_k, dthick_k);
     long long it = 0;
     while (delta_mass > Tol<R>::mass) {
       if (++it > G->iter_cap) { status |= LGAR_ST_ITERCAP; break; }
@@ -663,12 +686,11 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
         psi = psi - (R(0.1) * factor);
         if (val(psi) < R(0.0) && val(psi_prev) != R(0.0)) psi = psi_prev * R(0.1);
       }
-      theta = theta_from_h<S, EX>(lk, psi);
+      theta = theta_from_h<S, POL>(lk, psi);
       S mass = S(R(0.0));
       mass = mass + (dthick_k * (theta - dth_k));
 #pragma unroll
-      for (int j = 0; j < NL - 1; j++)
-        if (j < k) mass = mass + dthick[j] * (theta_from_h<S, EX>(pick_static(P, j), psi) - dth[j]);
+      for (int j = 0; j < K; j++) mass = mass + dthick[j] * (theta_from_h<S, POL>(pick_static(P, j), psi) - dth[j]);
       new_mass = mass;
       delta_mass = ab(val(new_mass) - val(prior_mass));
       if (ab(val(psi) - val(psi_prev)) < Tol<R>::nochange && factor < R(1e-13)) break;
@@ -746,105 +768,119 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
   // populate_delta_thickness :177-209).  The reference snapshots every front first (copy_states); the
   // sweep runs deepest -> shallowest and front i only needs the pre-sweep values of i and i+1, so the
   // snapshot is two register triples carried down the sweep instead of a second front table.
-  // in-layer (layer > 0) and base-case fronts both end in the psi line search: one shared call site.
-  __device__ __forceinline__ void move_sweep(S infiltration, S aet, S old_mass, int fdd) {
-    const int nf0 = nf;
-    S on_z = S(R(0.0)), on_th = S(R(0.0)), on_ps = S(R(0.0));  // pre-sweep values of front i+1
-    int last = nf0 - 1;                                          // last front of the current layer's list
-    for (int i = nf0 - 1; i >= 0; i--) {
-      const int k = F.layer(i);
-      if (i < nf0 - 1 && F.layer(i + 1) != k) last = i;
+  // The sweep is LAYER-MAJOR with the layer index a compile-time constant: for K = NL-1 .. 0 the lane walks up its
+  // fronts tagged K.  Per-layer parameters are then plain register operands (no value-selects per front), the
+  // "layers above" loops have static bounds, and layer 0's cheap closed-form update carries no search code.
+  struct SweepCarry {
+    int i, nf0, fdd;
+    S infiltration, aet;
+    S on_z, on_th, on_ps;  // pre-sweep values of front i+1
+  };
+
+  template <int K> __device__ __forceinline__ void sweep_layer(SweepCarry &c) {
+    const LayerK<S> lk = pick_static(P, K);
+    const int last = c.i;  // deepest front of this layer's list (if the lane has fronts tagged K)
+    while (c.i >= 0 && F.layer(c.i) == K) {
+      const int i = c.i;
       const S oc_z = F.Z(i), oc_th = F.TH(i), oc_ps = F.PS(i);  // pre-sweep values of front i
-      const LayerK<S> lk = pick(P, k);
-      bool need_search = false, need_psi = false;
-      S t_psi = S(R(0.0)), t_new = S(R(0.0)), t_prior = S(R(0.0)), t_dth_k = S(R(0.0)), t_dthick_k = S(R(0.0));
-      S dth[NL], dthick[NL];
-#pragma unroll
-      for (int j = 0; j < NL; j++) { dth[j] = S(R(0.0)); dthick[j] = S(R(0.0)); }
-      if (i < nf0 - 1) {
+      bool need_psi = false;
+      if (i < c.nf0 - 1) {
         if (i == last || feq(i, last)) {
           // deepest front of a layer: psi continuity with the layer below
-          F.TH(i) = theta_from_h<S, EX>(lk, F.PS(i + 1));
+          F.TH(i) = theta_from_h<S, POL>(lk, F.PS(i + 1));
           F.PS(i) = F.PS(i + 1);
-        } else if (k == 0) {
-          S prior_mass = oc_z * (oc_th - on_th);
-          if (i == fdd || feq(fdd, i)) prior_mass = prior_mass + (infiltration - (R(0.0) + aet));
+        } else if constexpr (K == 0) {
+          S prior_mass = oc_z * (oc_th - c.on_th);
+          if (i == c.fdd || feq(c.fdd, i)) prior_mass = prior_mass + (c.infiltration - (R(0.0) + c.aet));
           S z = F.Z(i) + (F.DZ(i) * G->dt_h);
           z = mn(z, P.cum[NL - 1]);
           F.Z(i) = z;
           bool zero_dzdt = ab(val(F.DZ(i))) <= R(1e-8);  // torch.isclose(dzdt, 0, rtol=1e-8): atol 1e-8
           if (!(zero_dzdt && !F.bottom(i))) {            // a just-created front keeps its theta (Layer.py:458-467)
-            S potential = (prior_mass / z) + F.TH(i + 1);
+            S potential = dv<POL>(prior_mass, z) + F.TH(i + 1);
             F.TH(i) = mn(lk.te, potential);
           }
           need_psi = true;
         } else {
-          S prev_thick = cum_prev(k);
+          S dth[NL], dthick[NL];
+          const S prev_thick = P.cum[(K > 0) ? K - 1 : 0];
           S z = F.Z(i) + (F.DZ(i) * G->dt_h);
           F.Z(i) = z;
-          S psi_old = oc_ps, psi_below_old = on_ps;
+          S psi_old = oc_ps, psi_below_old = c.on_ps;
           S psi = F.PS(i), psi_below = F.PS(i + 1);
-          S prior_mass = (oc_z - prev_thick) * (oc_th - on_th);
+          S prior_mass = (oc_z - prev_thick) * (oc_th - c.on_th);
           S new_mass = (z - prev_thick) * (F.TH(i) - F.TH(i + 1));
 #pragma unroll
-          for (int j = 0; j < NL - 1; j++) {
-            if (j < k) {
-              const LayerK<S> lj = pick_static(P, j);
-              S theta_old = theta_from_h<S, EX>(lj, psi_old);
-              S theta_below_old = theta_from_h<S, EX>(lj, psi_below_old);
-              S lt = P.cum[j] - R(0.0);  // quirk: cumulative thickness (Layer.py:603-604)
-              prior_mass = prior_mass + (lt * (theta_old - theta_below_old));
-              S theta = theta_from_h<S, EX>(lj, psi);
-              S theta_below = theta_from_h<S, EX>(lj, psi_below);
-              new_mass = new_mass + (lt * (theta - theta_below));
-              dth[j] = theta_below;
-              dthick[j] = lt;
-            }
+          for (int j = 0; j < K; j++) {
+            const LayerK<S> lj = pick_static(P, j);
+            S theta_old = theta_from_h<S, POL>(lj, psi_old);
+            S theta_below_old = theta_from_h<S, POL>(lj, psi_below_old);
+            S lt = P.cum[j] - R(0.0);  // quirk: cumulative thickness (Layer.py:603-604)
+            prior_mass = prior_mass + (lt * (theta_old - theta_below_old));
+            S theta = theta_from_h<S, POL>(lj, psi);
+            S theta_below = theta_from_h<S, POL>(lj, psi_below);
+            new_mass = new_mass + (lt * (theta - theta_below));
+            dth[j] = theta_below;
+            dthick[j] = lt;
           }
-          t_dth_k = F.TH(i + 1);
-          t_dthick_k = z - prev_thick;
-          if (i == fdd || feq(fdd, i)) prior_mass = prior_mass + infiltration - (R(0.0) + aet);
-          t_psi = psi; t_new = new_mass; t_prior = prior_mass;
-          need_search = true;
-        }
-      } else if (nf0 == NL && k == NL - 1) {
-        // base_case: one front per layer, uniform psi
-        S z = F.Z(i) + F.DZ(i) * G->dt_h;
-        F.Z(i) = z;
-        S psi_old = oc_ps;
-        S psi = F.PS(i);
-        S base = P.cum[NL - 2];
-        S prior_mass = (oc_z - base) * (oc_th - R(0.0));
-        S new_mass = (z - base) * (F.TH(i) - R(0.0));
-#pragma unroll
-        for (int j = 0; j < NL - 1; j++) {
-          const LayerK<S> lj = pick_static(P, j);
-          S theta_old = theta_from_h<S, EX>(lj, psi_old);
-          prior_mass = prior_mass + P.thick[j] * (theta_old - R(0.0));
-          S theta = theta_from_h<S, EX>(lj, psi);
-          new_mass = new_mass + P.thick[j] * (theta - R(0.0));
-          dthick[j] = P.thick[j];
-        }
-        if (F.layer(fdd) == NL - 1) prior_mass = prior_mass + infiltration - (R(0.0) + aet);
-        t_dthick_k = z - base;
-        t_psi = psi; t_new = new_mass; t_prior = prior_mass;
-        need_search = true;
-      }
-      if (__builtin_expect(need_search, 0)) {
+          const S t_dth_k = F.TH(i + 1);
+          const S t_dthick_k = z - prev_thick;
+          if (i == c.fdd || feq(c.fdd, i)) prior_mass = prior_mass + c.infiltration - (R(0.0) + c.aet);
 #ifdef LGAR_DUP_SEARCH
-        if constexpr (sizeof(S) == sizeof(R)) {
-          const S extra = theta_mass_balance(k, lk, opaque(t_psi), opaque(t_new), opaque(t_prior), dth, dthick, t_dth_k, t_dthick_k);
-          if (val(extra) == R(-1.0)) status |= LGAR_ST_STRUCT;  // never true
-        }
+          if constexpr (sizeof(S) == sizeof(R)) {
+            const S extra = theta_mass_balance<K>(lk, opaque(psi), opaque(new_mass), opaque(prior_mass), dth, dthick, t_dth_k, t_dthick_k);
+            if (val(extra) == R(-1.0)) status |= LGAR_ST_STRUCT;  // never true
+          }
 #endif
-        S theta_new = theta_mass_balance(k, lk, t_psi, t_new, t_prior, dth, dthick, t_dth_k, t_dthick_k);
-        F.TH(i) = mn(theta_new, lk.te);
-        need_psi = true;
+          S theta_new = theta_mass_balance<K>(lk, psi, new_mass, prior_mass, dth, dthick, t_dth_k, t_dthick_k);
+          F.TH(i) = mn(theta_new, lk.te);
+          need_psi = true;
+        }
+      } else if constexpr (K == NL - 1) {
+        if (c.nf0 == NL) {
+          // base_case: one front per layer, uniform psi
+          S dth[NL], dthick[NL];
+#pragma unroll
+          for (int j = 0; j < NL; j++) { dth[j] = S(R(0.0)); dthick[j] = S(R(0.0)); }
+          S z = F.Z(i) + F.DZ(i) * G->dt_h;
+          F.Z(i) = z;
+          S psi_old = oc_ps;
+          S psi = F.PS(i);
+          S base = P.cum[NL - 2];
+          S prior_mass = (oc_z - base) * (oc_th - R(0.0));
+          S new_mass = (z - base) * (F.TH(i) - R(0.0));
+#pragma unroll
+          for (int j = 0; j < NL - 1; j++) {
+            const LayerK<S> lj = pick_static(P, j);
+            S theta_old = theta_from_h<S, POL>(lj, psi_old);
+            prior_mass = prior_mass + P.thick[j] * (theta_old - R(0.0));
+            S theta = theta_from_h<S, POL>(lj, psi);
+            new_mass = new_mass + P.thick[j] * (theta - R(0.0));
+            dthick[j] = P.thick[j];
+          }
+          if (F.layer(c.fdd) == NL - 1) prior_mass = prior_mass + c.infiltration - (R(0.0) + c.aet);
+          S theta_new = theta_mass_balance<NL - 1>(lk, psi, new_mass, prior_mass, dth, dthick, S(R(0.0)), z - base);
+          F.TH(i) = mn(theta_new, lk.te);
+          need_psi = true;
+        }
       }
-      if (need_psi) F.PS(i) = h_from_se<S, EX>(lk, se_from_theta(lk, F.TH(i)));
-      if (i == 0) check_column_mass(fdd, old_mass, infiltration, aet);
-      on_z = oc_z; on_th = oc_th; on_ps = oc_ps;
+      if (need_psi) F.PS(i) = h_from_se<S, POL>(lk, se_from_theta(lk, F.TH(i)));
+      c.on_z = oc_z; c.on_th = oc_th; c.on_ps = oc_ps;
+      c.i = i - 1;
     }
+  }
+  template <int K> __device__ __forceinline__ void sweep_from(SweepCarry &c) {
+    sweep_layer<K>(c);
+    if constexpr (K > 0) sweep_from<K - 1>(c);
+  }
+
+  __device__ __forceinline__ void move_sweep(S infiltration, S aet, S old_mass, int fdd) {
+    SweepCarry c;
+    c.i = nf - 1; c.nf0 = nf; c.fdd = fdd;
+    c.infiltration = infiltration; c.aet = aet;
+    c.on_z = c.on_th = c.on_ps = S(R(0.0));
+    sweep_from<NL - 1>(c);
+    check_column_mass(fdd, old_mass, infiltration, aet);  // after front 0 (Layer.py:1296-1305)
   }
 
   // merge_wetting_fronts / is_passing / pass_front / delete_front, Layer.py:826-892: per layer, the first
@@ -863,7 +899,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
       S mass = F.Z(i) * (F.TH(i) - F.TH(nx)) + F.Z(nx) * (F.TH(nx) - F.TH(nn));
       F.Z(i) = mass / (F.TH(i) - F.TH(nn));
       S se = se_from_theta(lk, F.TH(i));
-      F.PS(i) = h_from_se<S, EX>(lk, se);
+      F.PS(i) = h_from_se<S, POL>(lk, se);
       // delete_front: the first front of THIS layer's list that is value-equal to `next`
       int j = lo;
       while (j < nf && F.layer(j) == k && !feq(j, nx)) j++;
@@ -895,8 +931,8 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
       const LayerK<S> ln = pick(P, k + 1);
       S overshot = F.Z(i) - F.Z(nx);
       S se = se_from_theta(lk, F.TH(i));
-      F.PS(i) = h_from_se<S, EX>(lk, se);
-      S theta_new = theta_from_h<S, EX>(ln, F.PS(i));
+      F.PS(i) = h_from_se<S, POL>(lk, se);
+      S theta_new = theta_from_h<S, POL>(ln, F.PS(i));
       S mbal = overshot * (F.TH(i) - F.TH(nx));
       S zc = mbal / (theta_new - F.TH(nn));
       S depth_new = cumk + zc;
@@ -925,8 +961,8 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
       flux = (F.TH(i) - F.TH(nx)) * (F.Z(i) - F.Z(nx));
       F.TH(nx) = F.TH(i);
       S se = se_from_theta(lk, F.TH(i));
-      F.PS(nx) = h_from_se<S, EX>(lk, se);
-      k_deepest = k_from_se<S, EX>(lk, se);
+      F.PS(nx) = h_from_se<S, POL>(lk, se);
+      k_deepest = k_from_se<S, POL>(lk, se);
       fdel(i);
     }
     return flux;
@@ -952,14 +988,14 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
         else {
           const int lj = F.layer(found);
           const LayerK<S> lf = pick(P, lj);
-          F.PS(found) = h_from_se<S, EX>(lf, se_from_theta(lf, F.TH(found)));
+          F.PS(found) = h_from_se<S, POL>(lf, se_from_theta(lf, F.TH(found)));
           const S dry_th = F.TH(found), dry_ps = F.PS(found);
           for (int q = 0; q < nf; q++) {
             const int lq = F.layer(q);
             if (lq < lj) {  // quirk: EVERY front of all shallower layers is overwritten (Layer.py:1117-1143)
               const LayerK<S> lql = pick(P, lq);
-              F.PS(q) = h_from_se<S, EX>(lql, se_from_theta(lql, dry_th));
-              F.TH(q) = theta_from_h<S, EX>(lql, dry_ps);
+              F.PS(q) = h_from_se<S, POL>(lql, se_from_theta(lql, dry_th));
+              F.TH(q) = theta_from_h<S, POL>(lql, dry_ps);
             }
           }
         }
@@ -981,13 +1017,13 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
   __device__ __forceinline__ void update_psi() {
     for (int i = 0; i < nf - 1; i++) {
       const LayerK<S> lk = pick(P, F.layer(i));
-      F.PS(i) = h_from_se<S, EX>(lk, se_from_theta(lk, F.TH(i)));
+      F.PS(i) = h_from_se<S, POL>(lk, se_from_theta(lk, F.TH(i)));
     }
   }
 
   // K of front i as calc_dzdt / the state dump see it
   __device__ __forceinline__ S front_k(int i, const LayerK<S> &lk) const {
-    S k = k_from_se<S, EX>(lk, se_from_theta(lk, F.TH(i)));
+    S k = k_from_se<S, POL>(lk, se_from_theta(lk, F.TH(i)));
     if (i == 0 && new_front_frozen) k = k * G->frozen;
     return k;
   }
@@ -1019,6 +1055,10 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
     move_sweep(infiltration, aet, old_mass, fdd);
     S bottom_flux = S(R(0.0));
     // (a per-lane decision: a column's results must not depend on which other columns share its wave)
+#ifdef LGAR_DUP_EVENT
+    if (front_event_pending() && val(F.Z(0)) == R(-12345.0)) status |= LGAR_ST_STRUCT;  // never true
+    asm volatile("" ::: "memory");
+#endif
     if (__builtin_expect(front_event_pending(), 0)) {
       for (int pass = 0; pass < 2; pass++) {
         merge_fronts();
@@ -1058,19 +1098,19 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
         if (is_nan(val(g))) status |= LGAR_ST_NAN;
         const S ki = front_k(i, lk);
         if (k == 0) {
-          dzdt = R(1.0) / delta_theta * (lk.ksat * (g + h_p) / F.Z(i) + ki);
+          dzdt = dv<POL>(S(R(1.0)), delta_theta) * (dv<POL>(lk.ksat * (g + h_p), F.Z(i)) + ki);
         } else {
-          S den = S(R(0.0)) + (F.Z(i) - cum_prev(k)) / ki;
+          S den = S(R(0.0)) + dv<POL>(F.Z(i) - cum_prev(k), ki);
 #pragma unroll
           for (int j = 0; j < NL - 1; j++)
             if (j < k) {
               const LayerK<S> lj = pick_static(P, j);
-              S tl = theta_from_h<S, EX>(lj, F.PS(i));
-              S kl = k_from_se<S, EX>(lj, se_from_theta(lj, tl));
+              S tl = theta_from_h<S, POL>(lj, F.PS(i));
+              S kl = k_from_se<S, POL>(lj, se_from_theta(lj, tl));
               S pt = (j != 0) ? P.cum[(j > 0) ? j - 1 : 0] : S(R(0.0));
-              den = den + ((P.cum[j] - pt) / kl);
+              den = den + dv<POL>(P.cum[j] - pt, kl);
             }
-          dzdt = (R(1.0) / delta_theta) * ((F.Z(i) / den) + lk.ksat * (g + h_p) / F.Z(i));
+          dzdt = dv<POL>(S(R(1.0)), delta_theta) * (dv<POL>(F.Z(i), den) + dv<POL>(lk.ksat * (g + h_p), F.Z(i)));
         }
       }
       F.DZ(i) = dzdt;
@@ -1111,7 +1151,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
     F.Z(0) = dry_depth;
     F.TH(0) = theta_new;
     F.set_flag(0, 0, to_bottom);
-    F.PS(0) = h_from_se<S, EX>(l0, se_from_theta(l0, theta_new));
+    F.PS(0) = h_from_se<S, POL>(l0, se_from_theta(l0, theta_new));
     new_front_frozen = true;
     F.DZ(0) = S(R(0.0));
   }
@@ -1138,20 +1178,20 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
     if (is_nan(val(g))) status |= LGAR_ST_NAN | LGAR_ST_NEGBASE;
     S f_p;
     if (kfp == 0) {
-      f_p = P.ksat[0] * (R(1.0) + (g + h_p) / F.Z(fdd));
+      f_p = P.ksat[0] * (R(1.0) + dv<POL>(g + h_p, F.Z(fdd)));
     } else {
       S fd_ksat = lk.ksat * G->frozen;
-      S bottom_sum = (F.Z(fdd) - cum_prev(kfp)) / fd_ksat;
-      bottom_sum = bottom_sum + ((P.cum[0] - R(0.0)) / (P.ksat[0] * G->frozen));
+      S bottom_sum = dv<POL>(F.Z(fdd) - cum_prev(kfp), fd_ksat);
+      bottom_sum = bottom_sum + dv<POL>(P.cum[0] - R(0.0), P.ksat[0] * G->frozen);
 #pragma unroll
       for (int j = 1; j < NL - 1; j++)
         if (j < kfp) {
           const LayerK<S> lj = pick_static(P, j);
-          S tl = theta_from_h<S, EX>(lj, F.PS(fdd));
-          S kl = k_from_se<S, EX>(lj, se_from_theta(lj, tl));
-          bottom_sum = bottom_sum + ((P.cum[j] - P.cum[j - 1]) / kl);
+          S tl = theta_from_h<S, POL>(lj, F.PS(fdd));
+          S kl = k_from_se<S, POL>(lj, se_from_theta(lj, tl));
+          bottom_sum = bottom_sum + dv<POL>(P.cum[j] - P.cum[j - 1], kl);
         }
-      f_p = (F.Z(fdd) / bottom_sum) + ((g + h_p) * fd_ksat / F.Z(fdd));
+      f_p = dv<POL>(F.Z(fdd), bottom_sum) + dv<POL>((g + h_p) * fd_ksat, F.Z(fdd));
     }
     S pond_temp = ponded - f_p * dt;
     if (val(pond_temp) < R(0.0)) pond_temp = S(R(0.0));
@@ -1183,9 +1223,9 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
     for (int k = 0; k < NL; k++) {
       const LayerK<S> lk = pick_static(P, k);
       F.Z(k) = P.cum[k];
-      F.TH(k) = theta_from_h<S, EX>(lk, S(G->initial_psi));
+      F.TH(k) = theta_from_h<S, POL>(lk, S(G->initial_psi));
       F.PS(k) = S(G->initial_psi);
-      if (k == NL - 1) k_deepest = k_from_se<S, EX>(lk, se_from_theta(lk, F.TH(k)));
+      if (k == NL - 1) k_deepest = k_from_se<S, POL>(lk, se_from_theta(lk, F.TH(k)));
       F.DZ(k) = S(R(0.0));
       F.set_flag(k, k, true);
     }
@@ -1213,9 +1253,13 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
       S ponded_water_sub = S(R(0.0)), runoff_sub = S(R(0.0)), infiltration_sub = S(R(0.0)), AET_sub = S(R(0.0));
       // create_surficial_front predicate, models/dpLGAR.py:310-323
       const bool create = (val(previous_precip) == R(0.0)) && (val(precip_sub) > R(0.0)) && (val(ponded_water) == R(0.0));
+#ifdef LGAR_DUP_FDD
+      if (free_drainage_front() == 12345) status |= LGAR_ST_STRUCT;  // never true
+      asm volatile("" ::: "memory");
+#endif
       const int fdd = free_drainage_front();
       const bool saturated = val(F.TH(0)) >= val(P.te[0]);  // Layer.is_saturated, Layer.py:785-793
-      if (val(pet) > R(0.0)) AET_sub = aet_fn<S, EX>(pick_static(P, 0), pet, dt, F.PS(0), G->wp_psi);
+      if (val(pet) > R(0.0)) AET_sub = aet_fn<S, POL>(pick_static(P, 0), pet, dt, F.PS(0), G->wp_psi);
       a_precip = a_precip + precip_sub;
       a_pet = a_pet + ((val(pet_sub) > R(0.0)) ? pet_sub : S(R(0.0)));
       // Single call site for the front move (models/dpLGAR.py:199-266 re-ordered, same data flow): columns
@@ -1224,15 +1268,19 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
       // after the move is equivalent.
       const bool inserting = !create && val(ponded_depth_sub) > R(0.0);
       if (inserting) {
+#ifndef LGAR_ABL_NOINSERT
         insert_water(fdd, precip_sub, ponded_depth_sub, infiltration_sub, runoff_sub);
+#endif
         a_infil = a_infil + infiltration_sub;
         a_runoff = a_runoff + runoff_sub;
         ponded_water_sub = ponded_depth_sub;
       }
+#ifndef LGAR_ABL_NOMOVE
       if (!create || !saturated) {
         S perc_sub = move_wetting_front(create ? S(R(0.0)) : infiltration_sub, AET_sub, ending_volume_sub, fdd);
         if (!create) a_perc = a_perc + perc_sub;
       }
+#endif
       if (__builtin_expect(create && !saturated, 0)) {
         S dry_depth = calc_dry_depth();
         create_surficial_front(dry_depth, ponded_depth_sub, infiltration_sub);
@@ -1251,7 +1299,13 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
           a_runoff = a_runoff + runoff_sub;
         }
       }
+#ifndef LGAR_ABL_NODZDT
       calc_dzdt(ponded_depth_sub);
+#endif
+#ifdef LGAR_DUP_DZDT
+      asm volatile("" ::: "memory");
+      calc_dzdt(ponded_depth_sub);  // idempotent: a second pass recomputes the same dz/dt (Geff included)
+#endif
 #ifdef LGAR_DUP_MB
       ending_volume_sub = mass_balance();
       asm volatile("" ::: "memory");

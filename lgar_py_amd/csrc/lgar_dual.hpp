@@ -52,6 +52,10 @@ template <typename R> __device__ __forceinline__ Dual<R> pw(const Dual<R> &x, co
   if (x.v > R(0)) d = v * (y.d * (R(0.6931471805599453) * l2) + y.v * x.d / x.v);
   return Dual<R>(v, d);
 }
+// division policy (dv in lgar_device.hpp): dual numbers always divide exactly
+template <int POL, typename R> __device__ __forceinline__ Dual<R> dv(const Dual<R> &a, const Dual<R> &b) { return a / b; }
+template <int POL, typename R> __device__ __forceinline__ Dual<R> dv(const Dual<R> &a, R b) { return a / b; }
+template <int POL, typename R> __device__ __forceinline__ Dual<R> dv(R a, const Dual<R> &b) { return a / b; }
 // verification mode (see pwx in lgar_device.hpp): correctly rounded pow / log for the value and the derivative
 template <bool EX, typename R> __device__ __forceinline__ Dual<R> pwx(const Dual<R> &x, const Dual<R> &y) {
   if constexpr (EX && sizeof(R) == 8) {

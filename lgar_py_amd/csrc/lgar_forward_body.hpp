@@ -232,11 +232,13 @@ __device__ __forceinline__ void forward_lane(const LGAR_KARG KArgs<R> *ap, size_
     if (active) col.forward(precip, pet);
     const R acc[LGAR_NACC] = {col.a_precip, col.a_pet, col.a_aet, col.a_infil, col.a_runoff,
                               col.a_perc, col.a_giuh, col.a_disch, col.ponded_water, col.ending_volume};
+#ifndef LGAR_ABL_NOEPILOGUE
     if (live && active) {
 #pragma unroll
       for (int j = 0; j < LGAR_NACC; j++)
         if (a.series[j]) a.series[j][o] = acc[j];
     }
+#endif
     if (basin_on) {
       // basin aggregation in the epilogue of the step (physics/MassBalance.py:77-108 over many columns)
       const double w = active ? wgt : 0.0;

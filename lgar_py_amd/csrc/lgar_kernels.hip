@@ -38,7 +38,7 @@ template <typename R> __global__ void lgar_leaf_kernel(LeafArgs<R> a) {
     case 3: r = h_from_se(l, x); break;
     case 4: r = geff(l, x, y, a.nint); break;
     case 5: r = aet_fn(l, y, a.z, x, a.wp_psi); break;
-    case 6: r = geff_literal<R, sizeof(R) == 8>(l, x, y, a.nint); break;
+    case 6: r = geff_literal<R, (sizeof(R) == 8) ? 1 : 0>(l, x, y, a.nint); break;
   }
   a.out[i] = r;
 }

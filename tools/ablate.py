@@ -18,6 +18,16 @@ VARIANTS = {
     "dup_geff": ["-DLGAR_DUP_GEFF"],
     "dup_search": ["-DLGAR_DUP_SEARCH"],
     "dup_mb": ["-DLGAR_DUP_MB"],
+    "dup_fdd": ["-DLGAR_DUP_FDD"],
+    "dup_event": ["-DLGAR_DUP_EVENT"],
+    "dup_dzdt": ["-DLGAR_DUP_DZDT"],
+    "nogeff": ["-DLGAR_ABL_NOGEFF"],
+    "nogeff_nodzdt": ["-DLGAR_ABL_NOGEFF", "-DLGAR_ABL_NODZDT"],
+    "nogeff_nomove": ["-DLGAR_ABL_NOGEFF", "-DLGAR_ABL_NOMOVE"],
+    "nogeff_noinsert": ["-DLGAR_ABL_NOGEFF", "-DLGAR_ABL_NOINSERT"],
+    "nogeff_noepi": ["-DLGAR_ABL_NOGEFF", "-DLGAR_ABL_NOEPILOGUE"],
+    "skeleton": ["-DLGAR_ABL_NOGEFF", "-DLGAR_ABL_NODZDT", "-DLGAR_ABL_NOMOVE", "-DLGAR_ABL_NOINSERT", "-DLGAR_ABL_NOEPILOGUE"],
+    "contract": ["-ffp-contract=fast"],
     "occ3": ["-DLGAR_OCC_F32_SMALL=3"],
     "occ2": ["-DLGAR_OCC_F32_SMALL=2"],
     "occ1_f64": ["-DLGAR_OCC_F64_SMALL=1"],
