@@ -91,6 +91,12 @@ typedef struct {
   double frozen_factor;      /* cfg.constants.frozen_factor */
   double giuh[LGAR_GMAX];    /* cfg.data.giuh_ordinates */
   int64_t iter_cap;          /* cap on the reference's unbounded line searches (0 = default) */
+  int32_t forcing_columns;   /* columns of the forcing (and tangent-weight) arrays: 0 or n_columns = one forcing column per
+                                soil column; a divisor Nf of n_columns = broadcast, soil column c reads forcing column c % Nf
+                                (Nf = 1: one basin series for every column, the reference's Data yields exactly that,
+                                data/Data.py:32-37; the differentiable path lays its parameter directions side by side this
+                                way without replicating the forcing) */
+  int32_t reserved2;
 } LgarDims;
 
 /* Per-column soil parameters, each [n_layers][n_columns].  Replaces dpLGAR.alpha/.n/.ksat
@@ -118,7 +124,7 @@ typedef struct {
                                             one workgroup per block. */
 } LgarState;
 
-/* Forcing, each [n_steps][n_columns], cm/h (data/Data.py:32-37). */
+/* Forcing, each [n_steps][forcing_columns], cm/h (data/Data.py:32-37). */
 typedef struct {
   const void *precip, *pet;
 } LgarForcing;

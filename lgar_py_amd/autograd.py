@@ -18,46 +18,51 @@ from ._capi import ST_FAULT_MASK
 from .engine import LgarEngine, LgarError, LgarStatusError
 
 KINDS = ("alpha", "n", "ksat")
-# below this many (column, direction) pairs all directions of a backward pass ride as extra columns of ONE tangent
-# launch (latency-bound small jobs: the reference's single-column training loop); above it one launch per direction
-BATCH_DIRECTIONS_MAX_COLUMNS = 1 << 16
+# all directions of a backward pass ride side by side as extra columns of ONE tangent launch (direction-major: column
+# b * N + c integrates column c's parameters perturbed in direction b); forcing and weights are NOT replicated -- the kernels
+# broadcast them (LgarDims.forcing_columns = N).  Above this many (column, direction) pairs the directions go in groups.
+BATCH_DIRECTIONS_MAX_COLUMNS = 1 << 23
 
 
 def parameter_vjp(eng, precip, pet, w_runoff, w_perc, wanted, check=True):
     """Vector-Jacobian product for every (kind, layer) in `wanted` (list of (kind, l)).
-    Returns ({(kind, l): grad[N]}, tangent_status[N]).  Columns are independent, so for small jobs the directions are laid
-    side by side as len(wanted) * N columns of a single launch; large jobs loop over directions (same total work,
-    N-column memory).  A column whose tangent integration faults (status != 0: NaN, iteration cap, front overflow ...)
-    has no valid gradient: with check=True that raises LgarStatusError (a ValueError, like the reference's physics
+    Returns ({(kind, l): grad[N]}, tangent_status[N]).  Columns are independent, so the directions are laid side by side as
+    len(wanted) * N columns of a single launch (fills the chip even for ensembles of 10^5 columns; very large jobs go in
+    groups of directions).  A column whose tangent integration faults (status != 0: NaN, iteration cap, front overflow
+    ...) has no valid gradient: with check=True that raises LgarStatusError (a ValueError, like the reference's physics
     faults), with check=False its gradient entries are zeroed and the status tensor says which columns those are."""
     L, N, D = eng.L, eng.N, len(wanted)
     out = {}
     status = torch.zeros(N, dtype=torch.int32, device=eng.device)
     if D == 0:
         return out, status
-    if D * N <= BATCH_DIRECTIONS_MAX_COLUMNS and D > 1:
-        rep = lambda t: t.repeat(1, D)
-        d = eng.dims
+    group = max(1, min(D, BATCH_DIRECTIONS_MAX_COLUMNS // max(N, 1)))
+    d = eng.dims
+    for g0 in range(0, D, group):
+        part = wanted[g0:g0 + group]
+        Dg = len(part)
+        if Dg == 1:
+            kind, l = part[0]
+            dmat = torch.zeros(L, N, dtype=eng.dtype, device=eng.device)
+            dmat[l] = 1.0
+            out[(kind, l)], _, st = eng.tangent({kind: dmat}, precip, pet, w_runoff=w_runoff, w_perc=w_perc)
+            status |= st
+            continue
+        rep = lambda t: t.repeat(1, Dg)
         big = LgarEngine(rep(eng.alpha), rep(eng.n), rep(eng.ksat), rep(eng.theta_e), rep(eng.theta_r), rep(eng.thickness),
                          dt_h=d.dt_h, num_subcycles=d.num_subcycles, initial_psi=d.initial_psi,
                          ponded_depth_max=d.ponded_depth_max, wilting_point_psi=d.wilting_point_psi,
                          frozen_factor=d.frozen_factor, nint=d.nint, giuh_ordinates=tuple(d.giuh[i] for i in range(d.n_giuh)),
                          dtype=eng.dtype, device=eng.device, iter_cap=d.iter_cap, search_mode=d.search_mode,
-                         bottom_mode=d.bottom_mode, use_closed_form_G=bool(d.use_closed_form_G), front_slots=eng.front_slots)
-        dirs = {k: torch.zeros(L, D * N, dtype=eng.dtype, device=eng.device) for k in KINDS}
-        for b, (kind, l) in enumerate(wanted):
+                         bottom_mode=d.bottom_mode, use_closed_form_G=bool(d.use_closed_form_G), front_slots=eng.front_slots,
+                         with_state=False)
+        dirs = {k: torch.zeros(L, Dg * N, dtype=eng.dtype, device=eng.device) for k in KINDS}
+        for b, (kind, l) in enumerate(part):
             dirs[kind][l, b * N:(b + 1) * N] = 1.0
-        tile = lambda t: None if t is None else t.repeat(1, D)
-        g, _, st = big.tangent(dirs, tile(precip), tile(pet), w_runoff=tile(w_runoff), w_perc=tile(w_perc))
-        for b, key in enumerate(wanted):
+        g, _, st = big.tangent(dirs, precip, pet, w_runoff=w_runoff, w_perc=w_perc)  # forcing / weights broadcast by the kernel
+        for b, key in enumerate(part):
             out[key] = g[b * N:(b + 1) * N]
             status |= st[b * N:(b + 1) * N]
-    else:
-        for kind, l in wanted:
-            dmat = torch.zeros(L, N, dtype=eng.dtype, device=eng.device)
-            dmat[l] = 1.0
-            out[(kind, l)], _, st = eng.tangent({kind: dmat}, precip, pet, w_runoff=w_runoff, w_perc=w_perc)
-            status |= st
     status &= ST_FAULT_MASK
     bad = status != 0
     if bool(bad.any()):

@@ -17,6 +17,7 @@ namespace lgar {
 
 template <typename R> struct KArgs {
   int N, T, F;                                            // columns, forcing steps, rows of the per-front state arrays
+  int Nf;                                                 // forcing columns (N, or a divisor of N: broadcast c % Nf)
   unsigned *ticket;                                       // null, or the work counter of this launch (persistent waves)
   int chain_first, chain_last;                            // position in the capacity chain (see above)
   const R *alpha, *n, *ksat, *theta_e, *theta_r, *thick;  // [NL][N]
@@ -25,7 +26,7 @@ template <typename R> struct KArgs {
   int32_t *nf;                                            // [N]
   R *scalars;                                             // [NSCAL][N]
   R *totals;                                              // [NACC][N]
-  const R *precip, *pet;                                  // [T][N]
+  const R *precip, *pet;                                  // [T][Nf]
   R *series[LGAR_NACC];                                   // [T][N] or null
   double *basin;                                          // [NACC][T] or null
   const R *weights;                                       // [N] or null
@@ -214,13 +215,15 @@ __device__ __forceinline__ void forward_lane(const LGAR_KARG KArgs<R> *ap, size_
   // -- ~10^4 cycles of VALU work -- and at 128 VGPRs they end up as scratch traffic; the load latency of a step's own
   // forcing is covered by the other three waves of the SIMD.)
   const int T = a.T;
+  const size_t Nf = (size_t)a.Nf;
+  const size_t cf = (Nf == N) ? c : c % Nf;  // this column's forcing column
   for (int t = 0; t < T; t++) {
     ap = launder(ap);
     const LGAR_KARG KArgs<R> &a = *ap;  // (shadows the outer reference on purpose)
     col.G = &ap->G;
     const size_t o = (size_t)t * N + c;
-    const R precip = a.precip[o];
-    const R pet = a.pet[o];
+    const R precip = a.precip[(size_t)t * Nf + cf];
+    const R pet = a.pet[(size_t)t * Nf + cf];
     bool active = running && t >= t_begin;
     if (active && !a.chain_last && col.nf + a.G.nsub > FMAX) {
       // this step could outgrow the kernel's front capacity: hand the column over, state as of the end of step t-1

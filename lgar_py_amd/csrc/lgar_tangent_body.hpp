@@ -16,12 +16,12 @@
 namespace lgar {
 
 template <typename R> struct TArgs {
-  int N, T;
+  int N, T, Nf;  // Nf: columns of the forcing and weight arrays (N, or a divisor of N: broadcast c % Nf)
   int chain_first, chain_last;
   const R *alpha, *n, *ksat, *theta_e, *theta_r, *thick;  // [NL][N]
   const R *d_alpha, *d_n, *d_ksat;                        // [NL][N] or null
-  const R *precip, *pet;                                  // [T][N]
-  const R *w_runoff, *w_perc;                             // [T][N] or null
+  const R *precip, *pet;                                  // [T][Nf]
+  const R *w_runoff, *w_perc;                             // [T][Nf] or null
   R *grad_out;                                            // [N]
   R *tangent_runoff;                                      // [T][N] or null
   int32_t *status;                                        // [N]
@@ -57,8 +57,10 @@ __device__ __forceinline__ void tangent_lane(const LGAR_KARG TArgs<R> *ap, size_
   col.init_state();
   R grad = R(0);
   bool handed_over = false;
+  const size_t Nf = (size_t)a.Nf;
+  const size_t cf = (Nf == N) ? c : c % Nf;
   for (int t = 0; t < a.T; t++) {
-    const size_t o = (size_t)t * N + c;
+    const size_t o = (size_t)t * Nf + cf;
     if (!a.chain_last && col.nf + a.G.nsub > FMAX) {
       handed_over = true;  // could outgrow this kernel's front capacity: the next kernel redoes this column
       break;
@@ -66,7 +68,7 @@ __device__ __forceinline__ void tangent_lane(const LGAR_KARG TArgs<R> *ap, size_
     col.forward(S(a.precip[o]), S(a.pet[o]));
     if (a.w_runoff) grad += a.w_runoff[o] * col.a_runoff.d;
     if (a.w_perc) grad += a.w_perc[o] * col.a_perc.d;
-    if (a.tangent_runoff) a.tangent_runoff[o] = col.a_runoff.d;
+    if (a.tangent_runoff) a.tangent_runoff[(size_t)t * N + c] = col.a_runoff.d;
     col.drain();
   }
   a.grad_out[c] = handed_over ? R(0) : grad;

@@ -38,7 +38,7 @@ class LgarEngine:
     def __init__(self, alpha, n, ksat, theta_e, theta_r, thickness, *, n_columns=None, dt_h=1.0, num_subcycles=1,
                  initial_psi=2000.0, ponded_depth_max=0.0, wilting_point_psi=15495.0, frozen_factor=1.0, nint=120,
                  giuh_ordinates=(0.06, 0.51, 0.28, 0.12, 0.03), dtype=torch.float64, device="cuda:0",
-                 iter_cap=0, search_mode=1, bottom_mode=0, use_closed_form_G=False, front_slots=None):
+                 iter_cap=0, search_mode=1, bottom_mode=0, use_closed_form_G=False, front_slots=None, with_state=True):
         self.device = torch.device(device)
         _require_gpu(self.device)
         self.lib = _capi.load()
@@ -91,6 +91,12 @@ class LgarEngine:
         d.front_slots = FMAX
         self.front_slots = FMAX
 
+        self.status = torch.zeros(N, dtype=torch.int32, device=self.device)
+        if not with_state:  # tangent-only engine (autograd.parameter_vjp): the tangent kernels keep no state in HBM
+            self._params = _capi.LgarParams(*[t.data_ptr() for t in (self.alpha, self.n, self.ksat, self.theta_e,
+                                                                     self.theta_r, self.thickness)])
+            self._state = None
+            return
         z = lambda *shape, dt=dtype: torch.zeros(*shape, dtype=dt, device=self.device)
         self.depth, self.theta, self.psi = z(FMAX, N), z(FMAX, N), z(FMAX, N)
         self.k, self.dzdt = z(FMAX, N), z(FMAX, N)
@@ -98,7 +104,6 @@ class LgarEngine:
         self.n_fronts = z(N, dt=torch.int32)
         self.scalars = z(NSCAL, N)
         self.totals = z(NACC, N)
-        self.status = z(N, dt=torch.int32)
         self.counters = z(_capi.NCOUNTERS, dt=torch.int64)
         self.tickets = z(_capi.NTICKETS, dt=torch.int32)  # work counters of the persistent-wave schedule
 
@@ -122,20 +127,25 @@ class LgarEngine:
 
     def forward(self, precip, pet, series=("runoff", "percolation"), out=None, check=True, basin=(), weights=None,
                 call_sums=False):
-        """Advance every column by T forcing steps.  precip/pet: [T, N] cm/h on self.device.
+        """Advance every column by T forcing steps.  precip/pet: [T, N] cm/h on self.device, or [T, Nf] with Nf dividing N
+        (broadcast: column c reads forcing column c % Nf; Nf = 1 is one basin series for every column).
 
         Returns {name: tensor[T, N]} for the requested per-step series (the model accumulators as they
         stand after each forward(), before MassBalance.change_mass zeroes them).  basin: names whose per-step sum over
         this engine's columns (optionally weighted by weights[N]) is reduced inside the kernel; returned under
         "basin:<name>" as fp64 [T] tensors.  call_sums=True adds "call_sums": [NACC, N], the accumulators summed over this
         call's steps (rows 8, 9: latest ponded_water / ending_volume)."""
+        if self._state is None:
+            raise LgarError("this engine was created with with_state=False (tangent launches only)")
         precip = torch.as_tensor(precip).to(self.device, self.dtype).contiguous()
         pet = torch.as_tensor(pet).to(self.device, self.dtype).contiguous()
         if precip.dim() == 1:
             precip, pet = precip[None, :], pet[None, :]
-        if precip.shape != pet.shape or precip.shape[1] != self.N:
-            raise LgarError("forcing must be [T, %d]; got %s / %s" % (self.N, tuple(precip.shape), tuple(pet.shape)))
+        if precip.shape != pet.shape or precip.dim() != 2 or precip.shape[1] < 1 or self.N % precip.shape[1] != 0:
+            raise LgarError("forcing must be [T, %d] (or [T, Nf] with Nf dividing it: column c reads forcing column c %% Nf); "
+                            "got %s / %s" % (self.N, tuple(precip.shape), tuple(pet.shape)))
         T = precip.shape[0]
+        self.dims.forcing_columns = precip.shape[1]
         res = {}
         so = _capi.LgarStepOut()
         for nm in series:
@@ -176,17 +186,20 @@ class LgarEngine:
         """Forward-mode tangent from a FRESH state (set_internal_states) over the whole forcing series.
 
         direction: {"alpha" | "n" | "ksat": [L, N] tensor} -- the parameter perturbation (missing = 0).
+        precip / pet / w_runoff / w_perc: [T, N], or all [T, Nf] with Nf dividing N (column c uses column c % Nf of each).
         Returns (grad[N], tangent_runoff[T, N] or None, status[N]) with
         grad[c] = sum_t w_runoff[t, c] * d runoff_t[c] + w_perc[t, c] * d percolation_t[c].  status != 0 marks columns whose
         tangent integration faulted (their grad entry is not a gradient): callers must check it (autograd.parameter_vjp does)."""
         prep = lambda t: None if t is None else torch.as_tensor(t).to(self.device, self.dtype).contiguous()
         precip, pet, w_runoff, w_perc = prep(precip), prep(pet), prep(w_runoff), prep(w_perc)
-        if precip.dim() != 2 or precip.shape[1] != self.N or pet.shape != precip.shape:
-            raise LgarError("forcing must be [T, %d]; got %s / %s" % (self.N, tuple(precip.shape), tuple(pet.shape)))
+        if precip.dim() != 2 or precip.shape[1] < 1 or self.N % precip.shape[1] != 0 or pet.shape != precip.shape:
+            raise LgarError("forcing must be [T, %d] or [T, Nf] with Nf dividing it; got %s / %s"
+                            % (self.N, tuple(precip.shape), tuple(pet.shape)))
         for nm, w in (("w_runoff", w_runoff), ("w_perc", w_perc)):
             if w is not None and w.shape != precip.shape:
                 raise LgarError("%s must be [T, N] like the forcing; got %s" % (nm, tuple(w.shape)))
         T = precip.shape[0]
+        self.dims.forcing_columns = precip.shape[1]
         dirs = {k: prep(direction.get(k)) for k in ("alpha", "n", "ksat")}
         for k, v in dirs.items():
             if v is not None and tuple(v.shape) != (self.L, self.N):

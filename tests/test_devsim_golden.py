@@ -222,3 +222,34 @@ def test_columns_outside_the_reference_domain_are_flagged_like_the_oracle():
         ok = st == 0
         assert np.abs(out["runoff"][:, ok] - ro[:, ok]).max() <= 1e-6 * max(1.0, np.abs(ro).max()), mode
         assert _rel(eng.totals[:8][:, ok], acc[:8][:, ok], 1e-3).max() <= 1e-6, mode
+
+
+def test_forcing_broadcast_equals_replicated_forcing():
+    """LgarDims.forcing_columns: soil column c reads forcing column c % Nf.  One basin series for every column (Nf = 1, what
+    the reference's Data yields) and the direction-major layout of the differentiable path (Nf = N / D) give bitwise the
+    results of explicitly replicated forcing, forward and tangent."""
+    import devsim
+    g = np.load(os.path.join(GOLDEN, "synth0_phil_1500.npz"))
+    f = g["forcing"][:200]
+    N = 6
+    a = _engine(g, N)
+    full = a.forward(np.repeat(f[:, 0:1], N, 1), np.repeat(f[:, 1:2], N, 1), series=("runoff", "AET"))
+    b = _engine(g, N)
+    one = b.forward(f[:, 0:1], f[:, 1:2], series=("runoff", "AET"))
+    for nm in full:
+        assert np.array_equal(full[nm], one[nm])
+    assert np.array_equal(a.theta, b.theta) and np.array_equal(a.totals, b.totals)
+    sc = np.array([1.0, 0.5, 0.8])
+    pr3, pe3 = f[:, 0:1] * sc[None, :], f[:, 1:2] * np.ones((1, 3))
+    c = _engine(g, N)
+    half = c.forward(pr3, pe3, series=("runoff",))  # columns 0..2 and 3..5 see forcing columns 0..2
+    d = _engine(g, N)
+    rep = d.forward(np.tile(pr3, (1, 2)), np.tile(pe3, (1, 2)), series=("runoff",))
+    assert np.array_equal(half["runoff"], rep["runoff"])
+    w = np.linspace(0.5, 1.5, 200)[:, None] * np.ones((1, 3))
+    dirs = np.zeros((3, N))
+    dirs[0, :3] = 1.0   # first direction: layer-0 Ksat on columns 0..2
+    dirs[1, 3:] = 1.0   # second direction: layer-1 Ksat on columns 3..5 (same soils, same forcing)
+    g1, _, s1 = c.tangent({"ksat": dirs}, pr3, pe3, w_runoff=w)
+    g2, _, s2 = d.tangent({"ksat": dirs}, np.tile(pr3, (1, 2)), np.tile(pe3, (1, 2)), w_runoff=np.tile(w, (1, 2)))
+    assert np.array_equal(g1, g2) and (s1 == 0).all() and np.abs(g1).max() > 0

@@ -190,3 +190,23 @@ def test_in_kernel_basin_aggregation():
             outw = eng.forward(pr, pe, series=("runoff",), basin=("runoff",), weights=w, check=False)
             refw = (outw["runoff"].double() * w.to(outw["runoff"].device)[None, :]).sum(1)
             assert torch.allclose(outw["basin:runoff"], refw, rtol=tol * 10, atol=tol * 10 * float(refw.abs().max()))
+
+
+def test_forcing_broadcast_on_gpu():
+    """LgarDims.forcing_columns: [T, 1] basin forcing for every column (and [T, N/2]) equals replicated forcing bitwise."""
+    import lgar_py_amd as lg
+    g = np.load(os.path.join(GOLDEN, "phil_hourly_3000.npz"))
+    f = torch.tensor(g["forcing"][:400])
+    N = 200
+    kw = dict(n_columns=N, dt_h=1.0, ponded_depth_max=2.0, dtype=torch.float64)
+    a = lg.LgarEngine(g["alpha"], g["n"], g["ksat"], g["theta_e"], g["theta_r"], g["thickness"], **kw)
+    full = a.forward(f[:, 0:1].expand(-1, N).contiguous(), f[:, 1:2].expand(-1, N).contiguous(), series=("runoff", "AET"))
+    b = lg.LgarEngine(g["alpha"], g["n"], g["ksat"], g["theta_e"], g["theta_r"], g["thickness"], **kw)
+    one = b.forward(f[:, 0:1], f[:, 1:2], series=("runoff", "AET"))
+    for nm in full:
+        assert torch.equal(full[nm], one[nm]), nm
+    assert torch.equal(a.theta, b.theta)
+    ref = torch.tensor(g["acc"][:400, 2], device=one["AET"].device)
+    assert float((one["AET"][:, 7] - ref).abs().max()) <= 1e-6 * float(ref.abs().max())
+    with pytest.raises(lg.LgarError, match="dividing"):
+        b.forward(f[:, 0:1].expand(-1, 3).contiguous(), f[:, 1:2].expand(-1, 3).contiguous())
