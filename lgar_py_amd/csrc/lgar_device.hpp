@@ -247,21 +247,15 @@ template <typename S> __device__ __forceinline__ S geff(const LayerK<S> &l, S th
   return geff_literal<S, 0>(l, theta1, theta2, nint);
 }
 
-// fp32 Geff: the same 121 nodes with Se(h) -> K(Se) fused per node.  With a = (alpha h)^n:
-//   Se = (1+a)^-m,  Se^(1/m) = 1/(1+a),  1 - Se^(1/m) = a/(1+a),  sqrt(Se) = (1+a)^(-m/2)
-// so K = Ksat (1+a)^(-m/2) (1 - (a/(1+a))^m)^2 needs 2 v_log_f32 + 3 v_exp_f32 and no division, instead of
-// 4 pow + sqrt + divide.  (The 1e-12 nudge of calc_k_from_se applies only for a <= 1e-8, i.e. |h| far below the
-// 0.1 cm cut where Se is 1 anyway.)  Nodes are placed directly (h_i + (i+1) dh, last node = h_f): the running
-// sum drifts by ~nint ulps of h_i, cm-scale for very dry soil, and the last trapezoid dominates the integral.
+// Fused Geff (fp64, and the dual numbers of the differentiable path): the same 121 nodes with Se(h) -> K(Se) fused per
+// node.  With x = alpha h, a = x^n and n m = n - 1:
+//   P = x^(n-1) = a^m,  a = x P,  sqrt(Se) = (1+a)^(-m/2),  (a/(1+a))^m = P Se
+// so K = Ksat sqrt(Se) (1 - P Se)^2 needs 2 log2 + 2 exp2 and no division, instead of the reference's 4 pow + sqrt +
+// divide.  (The 1e-12 nudge of calc_k_from_se applies only for a <= 1e-8, i.e. |h| far below the 0.1 cm cut where Se is 1
+// anyway.)  fp64 keeps the reference's running sum h2 += dh; a float instantiation would place the nodes directly
+// (h_i + (i+1) dh, last node = h_f): its running sum drifts by ~nint ulps of h_i, cm-scale for very dry soil, and the last
+// trapezoid dominates the integral.  The plain-float kernels use the packed loop further down instead.
 #ifndef LGAR_NO_FUSED_GEFF
-// Fused Geff for plain reals: the same 121 nodes with Se(h) -> K(Se) fused per node.  With a = (alpha h)^n:
-//   Se = (1+a)^-m,  Se^(1/m) = 1/(1+a),  1 - Se^(1/m) = a/(1+a),  sqrt(Se) = (1+a)^(-m/2)
-// so K = Ksat (1+a)^(-m/2) (1 - (a/(1+a))^m)^2 needs 2 log2 + 3 exp2 and no division, instead of 4 pow + sqrt +
-// divide.  (The 1e-12 nudge of calc_k_from_se applies only for a <= 1e-8, i.e. |h| far below the 0.1 cm cut where Se
-// is 1 anyway.)  fp32 places the nodes directly (h_i + (i+1) dh, last node = h_f): its running sum drifts by ~nint
-// ulps of h_i, cm-scale for very dry soil, and the last trapezoid dominates the integral; fp64 keeps the
-// reference's running sum h2 += dh.
-
 template <typename S> __device__ __forceinline__ S geff_fused(const LayerK<S> &l, S theta1, S theta2, int nint) {
   using R = real_t<S>;
   const S se_i = se_from_theta(l, theta1);

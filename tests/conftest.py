@@ -32,5 +32,5 @@ def _devsim_libraries(request):
     """Build the device-code simulator (tests/devsim) for the layer counts the CPU tests use, concurrently, once."""
     if any("devsim" in str(item.fspath) for item in request.session.items):
         import devsim
-        devsim.prebuild((2, 3, 4))
+        devsim.prebuild((2, 3, 4, 5, 6))
     yield

@@ -427,6 +427,22 @@ for s in (5, 9):
                                                subcycle_s=300, forcing_res_s=300, endtime_h=12.0, grad=True))
 
 
+# five and six soil layers (the reference builds one Layer per entry of cfg.data.layer_thickness, Layer.py:77-89; the kernels
+# are compiled for 2..6)
+FIVE = dict(alpha=[0.0031297, 0.01, 0.0083272, 0.02, 0.0037454], n=[1.6858, 1.47, 1.299, 1.42, 1.6151],
+            ksat=[0.45, 0.504, 0.07, 0.3348, 0.45], theta_e=[0.4513, 0.40, 0.4773, 0.44, 0.4617],
+            theta_r=[0.0648, 0.06, 0.0831, 0.08, 0.0668], thickness=[20.0, 30.0, 60.0, 50.0, 40.0])
+SIX = dict(alpha=[0.01, 0.0031297, 0.01, 0.0083272, 0.02, 0.0037454], n=[1.66, 1.6858, 1.47, 1.299, 1.42, 1.6151],
+           ksat=[0.756, 0.45, 0.504, 0.07, 0.3348, 0.45], theta_e=[0.44, 0.4513, 0.40, 0.4773, 0.44, 0.4617],
+           theta_r=[0.07, 0.0648, 0.06, 0.0831, 0.08, 0.0668], thickness=[12.0, 18.0, 30.0, 60.0, 50.0, 30.0])
+CASES["five_layer_synth1"] = (run_case, dict(forcing="forcing_data_synth_1.txt", soil=FIVE, pdm=0.0, subcycle_s=300, forcing_res_s=300, endtime_h=12.0))
+CASES["five_layer_phil_500"] = (run_case, dict(forcing=PH, soil=FIVE, pdm=2, subcycle_s=3600, forcing_res_s=3600, endtime_h=500.0))
+CASES["six_layer_synth0_400"] = (run_case, dict(forcing="forcing_data_synth_0.csv", soil=SIX, pdm=0.0, subcycle_s=3600, forcing_res_s=3600, endtime_h=400.0))
+CASES["six_layer_synth1"] = (run_case, dict(forcing="forcing_data_synth_1.txt", soil=SIX, pdm=0.0, subcycle_s=300, forcing_res_s=300, endtime_h=12.0))
+CASES["six_layer_phil_300"] = (run_case, dict(forcing=PH, soil=SIX, pdm=2, subcycle_s=3600, forcing_res_s=3600, endtime_h=300.0))
+CASES["grad_six_layer_synth1"] = (run_case, dict(forcing="forcing_data_synth_1.txt", soil=SIX, pdm=0.0, subcycle_s=300, forcing_res_s=300, endtime_h=12.0, grad=True))
+
+
 def _run(name):
     fn, kw = CASES[name]
     try:
