@@ -104,7 +104,7 @@ __device__ __forceinline__ double lg2p(double x) { return log2(x); }
 __device__ __forceinline__ double ex2p(double x) { return exp2(x); }
 #else
 __device__ __forceinline__ double lg2p(double x) { return fast_log2_core(x); }
-__device__ __forceinline__ double ex2p(double x) { return fast_exp2_core(x); }
+__device__ __forceinline__ double ex2p(double x) { return fast_exp2_core<false>(x); }
 #endif
 __device__ __forceinline__ double sq(double x) { return sqrt(x); }
 __device__ __forceinline__ double ab(double x) { return fabs(x); }
@@ -270,15 +270,38 @@ template <typename S> __device__ __forceinline__ S geff_fused(const LayerK<S> &l
   S g = S(R(0.0));
   S k1 = k_from_se(l, se_i);
   S h2 = h_i + dh;
-  for (int i = 0; i < nint; i++) {
-    if (sizeof(R) == 4) h2 = (i + 1 >= nint) ? h_f : h_i + R(i + 1) * dh;
-    // four transcendentals per node: P = a^m = x^(n-1), a = x P, sqrt(Se) = (1+a)^(-m/2), (a/(1+a))^m = P Se
-    const S x = l.alpha * h2;
+  // four transcendentals per node: P = a^m = x^(n-1), a = x P, sqrt(Se) = (1+a)^(-m/2), (a/(1+a))^m = P Se
+  auto node = [&](const S &h) {
+    const S x = l.alpha * h;
     const S P = ex2p(nm1 * lg2p(x));
     const S l1 = lg2p(R(1.0) + x * P);
     const S sqrt_se = ex2p(half_m * l1);
     const S t = R(1.0) - P * (sqrt_se * sqrt_se);
-    S k2 = l.ksat * sqrt_se * (t * t);
+    return l.ksat * sqrt_se * (t * t);
+  };
+  // The |h| < 0.1 -> Se = 1 rule (utils.py:124-128) can only bind on a SUFFIX of the nodes (h falls monotonically from
+  // h_i to h_f): a wave-uniform count of leading nodes that no lane needs to test runs select-free.
+  const R jf = (val(h_i) - R(0.1)) / -val(dh) - R(2.0);
+  int safe = (jf > R(0.0)) ? ((jf < R(nint)) ? int(jf) : nint) : 0;  // NaN (dh == 0) -> 0
+  int n_safe = nint;
+  if (any_lane(safe < nint) != 0ull) {
+    n_safe = 0;
+    for (int bit = 128; bit; bit >>= 1) {
+      const int cand = n_safe + bit;
+      if (cand <= nint && any_lane(safe < cand) == 0ull) n_safe = cand;
+    }
+  }
+  int i = 0;
+  for (; i < n_safe; i++) {
+    if (sizeof(R) == 4) h2 = (i + 1 >= nint) ? h_f : h_i + R(i + 1) * dh;
+    const S k2 = node(h2);
+    g = g + ((k1 + k2) * hdh);
+    k1 = k2;
+    if (sizeof(R) != 4) h2 = h2 + dh;
+  }
+  for (; i < nint; i++) {
+    if (sizeof(R) == 4) h2 = (i + 1 >= nint) ? h_f : h_i + R(i + 1) * dh;
+    S k2 = node(h2);
     k2 = (ab(val(h2)) < R(0.1) || val(h2) < R(0.0)) ? k_sat1 : k2;
     g = g + ((k1 + k2) * hdh);
     k1 = k2;

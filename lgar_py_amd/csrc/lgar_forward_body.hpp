@@ -39,10 +39,10 @@ template <typename R> struct KArgs {
 
 // Per-call sums of the accumulators that fit in the wave's LDS budget next to the front table.  They are touched once per
 // forcing step, which makes them the register allocator's first spill victims -- and a spilled read-modify-write is
-// scratch (HBM) write traffic on every step.  The 8-slot fp32 kernel has 10 KB per wave at 4 waves/SIMD: 8.7 KB of
-// fronts + 5 rows of sums; the remaining sums stay in registers.
+// scratch (HBM) write traffic on every step.  The 8-slot kernels have 10 KB (fp32, 4 waves/SIMD) / 20 KB (fp64, 2 waves/SIMD)
+// of LDS per wave: 8.7 / 16.9 KB of fronts + 5 rows of sums; the remaining sums stay in registers.
 template <typename S, int FMAX> struct LdsSums {
-  static constexpr int rows = (sizeof(S) == 4 && FMAX <= LGAR_CAP_SMALL) ? 5 : 8;
+  static constexpr int rows = (FMAX <= LGAR_CAP_SMALL) ? 5 : 8;
 };
 
 template <typename S, int FMAX, int SUMROWS = LdsSums<S, FMAX>::rows> struct WaveLDS {

@@ -20,9 +20,10 @@
 
 namespace lgar {
 
-// 2^x for finite x and -inf .. +inf clamped; NaN is NOT preserved (callers that need NaN to survive use fast_exp2)
-__device__ __forceinline__ double fast_exp2_core(double x) {
-  const double xc = fmin(fmax(x, -1100.0), 1100.0);  // keeps the integer part in range; ldexp saturates to 0 / inf
+// 2^x for finite x and -inf .. +inf clamped (CLAMP = false: finite |x| < 2^31 only, as inside the Geff trapezoid, where the
+// exponent is a few thousand at most); NaN is NOT preserved (callers that need NaN to survive use fast_exp2)
+template <bool CLAMP = true> __device__ __forceinline__ double fast_exp2_core(double x) {
+  const double xc = CLAMP ? fmin(fmax(x, -1100.0), 1100.0) : x;  // keeps the integer part in range; ldexp saturates to 0 / inf
   const double k = rint(xc);
   const double f = xc - k;  // |f| <= 0.5, exact
   double p = 4.45581790833606449e-10;
@@ -42,7 +43,7 @@ __device__ __forceinline__ double fast_exp2_core(double x) {
 
 // 2^x, NaN in -> NaN out
 __device__ __forceinline__ double fast_exp2(double x) {
-  const double r = fast_exp2_core(x);
+  const double r = fast_exp2_core<true>(x);
   return (x != x) ? x : r;
 }
 

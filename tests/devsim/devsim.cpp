@@ -122,7 +122,7 @@ void devsim_math(int op, int n, const double *x, const double *y, double *out) {
       case 0: out[i] = fast_exp2(x[i]); break;
       case 1: out[i] = fast_log2(x[i]); break;
       case 2: out[i] = fast_pow(x[i], y[i]); break;
-      case 3: out[i] = fast_exp2_core(x[i]); break;
+      case 3: out[i] = fast_exp2_core<false>(x[i]); break;
       case 4: out[i] = fast_log2_core(x[i]); break;
     }
   }
