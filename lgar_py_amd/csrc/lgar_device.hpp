@@ -520,7 +520,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
   // new_front_frozen marks a front created in the current sub-step, whose K carries frozen_factor (Layer.py:1410-1412).
   S k_deepest;
   bool new_front_frozen;
-  unsigned *wave_geff_calls = nullptr;  // wave-level LDS word: Geff evaluations (measurement), may be null
+  bool count_geff = false;              // measurement: count wave-level Geff evaluations in the unused upper bits of `status`
   int cap = FMAX;                       // fronts this column may hold: min(kernel capacity, rows of the state arrays)
   // accumulators drained every forcing step (physics/MassBalance.py:45-53)
   S a_precip, a_pet, a_aet, a_infil, a_runoff, a_perc, a_giuh, a_disch;
@@ -529,11 +529,13 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
 
   __device__ __forceinline__ S cum_at(int k) const { return sel<S, NL>(P.cum, k); }
   // calc_geff (lgar/green_ampt.py:19-99): trapezoid or closed form, per cfg.data.use_closed_form_G
-  __device__ __forceinline__ S capillary_drive(const LayerK<S> &lk, S theta1, S theta2) const {
+  __device__ __forceinline__ S capillary_drive(const LayerK<S> &lk, S theta1, S theta2) {
 #ifdef LGAR_ABL_NOGEFF  // register-pressure experiments (tools/): what the allocator does without the trapezoid
     return theta1 * theta2 + lk.alpha;
 #endif
-    if (wave_geff_calls != nullptr && first_active_lane()) *wave_geff_calls += 1u;
+    // one lane per wave-level evaluation adds 1 above the fault bits (no register, no LDS word; summed over the wave at the
+    // end of the block): bits 8..31 of status are otherwise unused while a column is integrated
+    if (count_geff && first_active_lane()) status += (1 << LGAR_ST_STEP_SHIFT);
 #ifdef LGAR_DUP_GEFF
     if constexpr (sizeof(S) == sizeof(R)) {
       const S extra = geff(lk, opaque(theta1), opaque(theta2), G->nint);

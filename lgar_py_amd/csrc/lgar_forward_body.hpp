@@ -40,15 +40,20 @@ template <typename R> struct KArgs {
 // Per-call sums of the accumulators that fit in the wave's LDS budget next to the front table.  They are touched once per
 // forcing step, which makes them the register allocator's first spill victims -- and a spilled read-modify-write is
 // scratch (HBM) write traffic on every step.  The 8-slot kernels have 10 KB (fp32, 4 waves/SIMD) / 20 KB (fp64, 2 waves/SIMD)
-// of LDS per wave: 8.7 / 16.9 KB of fronts + 5 rows of sums; the remaining sums stay in registers.
+// of LDS per wave: 8.5 / 16.5 KB of fronts + 6 rows of sums = exactly 10 / 20 KB; percolation (zero in the reference's
+// mode) stays in a register, discharge is the same sum as giuh_runoff.
 template <typename S, int FMAX> struct LdsSums {
-  static constexpr int rows = (FMAX <= LGAR_CAP_SMALL) ? 5 : 8;
+  static constexpr int rows = (FMAX <= LGAR_CAP_SMALL) ? 6 : 8;
 };
+
+// LDS row of accumulator j's per-call sum, or -1 if it stays in a register: with 6 rows the one left out is percolation
+template <int SR> __device__ __forceinline__ constexpr int sum_row(int j) {
+  return (SR >= 8) ? (j < 8 ? j : -1) : ((j < 5) ? (j < SR ? j : -1) : ((j == 6 && SR >= 6) ? 5 : -1));
+}
 
 template <typename S, int FMAX, int SUMROWS = LdsSums<S, FMAX>::rows> struct WaveLDS {
   S f[4][FMAX][WAVE];
   unsigned char fl[FMAX][WAVE];
-  unsigned geff_calls;  // wave-level count of Geff evaluations (measurement)
   S sums[SUMROWS][WAVE];
 };
 
@@ -155,13 +160,14 @@ __device__ __forceinline__ void forward_lane(const LGAR_KARG KArgs<R> *ap, size_
   int status = a.status[c];
   // which step this lane starts at: 0 in the first kernel of the chain, the recorded step for a column handed over by
   // the previous kernel, never (T) for everybody else in a later kernel
-  int t_begin = 0;
+  // (Lane-varying conditions that live across the whole time loop are kept as two integers, t_begin and t_stop, not as
+  // booleans: a long-lived lane mask costs an SGPR pair each, and the SGPR file is what this kernel runs out of first.)
+  int t_begin = live ? 0 : a.T;  // padding lanes of a ragged tail wave never start: they only take part in wave reductions
   if (!a.chain_first) {
-    t_begin = (status & LGAR_ST_RESUME) ? (int)((unsigned)status >> LGAR_ST_STEP_SHIFT) : a.T;
+    t_begin = (live && (status & LGAR_ST_RESUME)) ? (int)((unsigned)status >> LGAR_ST_STEP_SHIFT) : a.T;
     if (any_lane(t_begin < a.T) == 0ull) return;  // nothing handed over to this wave
   }
   status &= LGAR_ST_FAULT_MASK;
-  const bool mine = t_begin < a.T;
   ColParams<R, NL> P;
   load_params<R, NL>(a, c, P);
   Column<R, NL, FMAX, MODE> col(P, &ap->G, make_view<R, FMAX>(&lds.f[0][0][0], &lds.fl[0][0], lane));
@@ -188,8 +194,7 @@ __device__ __forceinline__ void forward_lane(const LGAR_KARG KArgs<R> *ap, size_
   col.k_deepest = (nf > 0) ? a.k[(size_t)(nf - 1) * N + c] : R(0);
   col.new_front_frozen = false;
   col.cap = FMAX < a.F ? FMAX : a.F;
-  col.wave_geff_calls = &lds.geff_calls;
-  if (lane == 0) lds.geff_calls = 0u;
+  col.count_geff = a.counters != nullptr;
   col.drain();
   // accumulators summed over the steps this kernel integrates: the first SR in LDS, the rest in registers
   constexpr int SR = LdsSums<R, FMAX>::rows;
@@ -200,17 +205,17 @@ __device__ __forceinline__ void forward_lane(const LGAR_KARG KArgs<R> *ap, size_
     if (j < SR) lds.sums[j][lane] = R(0);
   }
   double wgt = 0.0;
-  if (basin_on) wgt = live ? (a.weights ? (double)a.weights[c] : 1.0) : 0.0;
+  if (basin_on) wgt = a.weights ? (double)a.weights[c] : 1.0;
 
-  bool running = mine;      // false once the column is handed to the next kernel of the chain
-  int t_handover = a.T;
-  bool untouched = false;   // stopped before its first step: the state in HBM is left as it is
-  if (mine && nf_stored > cap) {
+  // the column is integrated for steps t_begin <= t < t_stop; t_stop < T: handed to the next kernel of the chain at
+  // t_stop (or, t_stop = -1, stopped for good before its first step); t_stop <= t_begin: the state in HBM is left as it is
+  int t_stop = a.T;
+  bool overflow_on_load = false;
+  if (t_begin < a.T && nf_stored > cap) {
     // more fronts than this kernel can hold: next kernel of the chain, or (last kernel) front overflow
-    running = false;
-    untouched = true;
-    if (a.chain_last) col.status |= LGAR_ST_OVERFLOW; else t_handover = t_begin;
+    if (a.chain_last) { overflow_on_load = true; t_stop = -1; } else t_stop = t_begin;
   }
+  if (overflow_on_load) col.status |= LGAR_ST_OVERFLOW;
   // (No software prefetch of the next step's forcing: the two values would have to live in registers across a whole step
   // -- ~10^4 cycles of VALU work -- and at 128 VGPRs they end up as scratch traffic; the load latency of a step's own
   // forcing is covered by the other three waves of the SIMD.)
@@ -224,19 +229,18 @@ __device__ __forceinline__ void forward_lane(const LGAR_KARG KArgs<R> *ap, size_
     const size_t o = (size_t)t * N + c;
     const R precip = a.precip[(size_t)t * Nf + cf];
     const R pet = a.pet[(size_t)t * Nf + cf];
-    bool active = running && t >= t_begin;
+    bool active = (t >= t_begin) && (t < t_stop);
     if (active && !a.chain_last && col.nf + a.G.nsub > FMAX) {
       // this step could outgrow the kernel's front capacity: hand the column over, state as of the end of step t-1
-      running = active = false;
-      t_handover = t;
-      untouched = (t == t_begin);
+      active = false;
+      t_stop = t;
     }
     if (any_lane(active) == 0ull) continue;
     if (active) col.forward(precip, pet);
     const R acc[LGAR_NACC] = {col.a_precip, col.a_pet, col.a_aet, col.a_infil, col.a_runoff,
                               col.a_perc, col.a_giuh, col.a_disch, col.ponded_water, col.ending_volume};
 #ifndef LGAR_ABL_NOEPILOGUE
-    if (live && active) {
+    if (active) {
 #pragma unroll
       for (int j = 0; j < LGAR_NACC; j++)
         if (a.series[j]) a.series[j][o] = acc[j];
@@ -256,7 +260,8 @@ __device__ __forceinline__ void forward_lane(const LGAR_KARG KArgs<R> *ap, size_
 #pragma unroll
       for (int j = 0; j < 7; j++) {  // MassBalance.change_mass, MassBalance.py:31-44
         if (j == 5 && a.G.bottom_mode == 0) continue;  // percolation is identically zero in the reference's mode
-        if (j < SR) lds.sums[j][lane] = lds.sums[j][lane] + acc[j];
+        const int row = sum_row<SR>(j);
+        if (row >= 0) lds.sums[row][lane] = lds.sums[row][lane] + acc[j];
         else tot[j] = tot[j] + acc[j];
       }  // (discharge [7] is the same sum as giuh_runoff [6]: both gain the same routed runoff, models/dpLGAR.py:293-297)
       col.drain();
@@ -265,13 +270,16 @@ __device__ __forceinline__ void forward_lane(const LGAR_KARG KArgs<R> *ap, size_
   ap = launder(ap);
   const LGAR_KARG KArgs<R> &z = *ap;  // the epilogue re-reads what it needs
   if (z.counters != nullptr) {
-    // measurement: wave-level Geff evaluations (the dominant instruction stream) of this launch
-    if (lane == 0 && lds.geff_calls) atomic_add(&z.counters[0], (unsigned long long)lds.geff_calls);
+    // measurement: wave-level Geff evaluations (the dominant instruction stream) of this block, counted above the fault
+    // bits of the lanes' status words
+    const double calls = wave_sum((double)((unsigned)col.status >> LGAR_ST_STEP_SHIFT));
+    if (lane == 0 && calls > 0.0) atomic_add(&z.counters[0], (unsigned long long)calls);
   }
-  if (!live || !mine) return;
+  col.status &= LGAR_ST_FAULT_MASK;
+  if (t_begin >= z.T) return;  // not this kernel's column (or a padding lane)
   int word = col.status;
-  if (t_handover < z.T) word |= LGAR_ST_RESUME | (int)((unsigned)t_handover << LGAR_ST_STEP_SHIFT);
-  if (untouched) {
+  if (t_stop >= 0 && t_stop < z.T) word |= LGAR_ST_RESUME | (int)((unsigned)t_stop << LGAR_ST_STEP_SHIFT);
+  if (t_stop <= t_begin) {
     z.status[c] = word;
     if (z.call_sums != nullptr && z.chain_first) {
 #pragma unroll
@@ -283,7 +291,8 @@ __device__ __forceinline__ void forward_lane(const LGAR_KARG KArgs<R> *ap, size_
   }
   store_state<R, NL, FMAX, MODE>(z, c, col, nf_before, word);
 #pragma unroll
-  for (int j = 0; j < SR && j < 7; j++) tot[j] = lds.sums[j][lane];
+  for (int j = 0; j < 7; j++)
+    if (sum_row<SR>(j) >= 0) tot[j] = lds.sums[sum_row<SR>(j)][lane];
   tot[7] = tot[6];
 #pragma unroll
   for (int j = 0; j < 8; j++) z.totals[j * N + c] = z.totals[j * N + c] + tot[j];  // MassBalance's run totals
