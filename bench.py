@@ -402,8 +402,9 @@ def main():
                 vr["achieved_geff_transcendentals"] = trans / (kern_ms * 1e-3)
                 peak_t = 0.5 * (probe["v_exp_f32"] + probe["v_log_f32"])
                 vr["frac_of_transcendental_peak"] = trans / (kern_ms * 1e-3) / peak_t if peak_t else None
-                mix_insts = geff_waves * ((nint - 1) // 2) * 18  # the loop body: 18 instructions per node pair
-                vr["frac_of_geff_mix_peak"] = mix_insts / (kern_ms * 1e-3) / probe["geff_mix"] if probe["geff_mix"] else None
+                vr["note"] = ("frac_of_transcendental_peak: the Geff trapezoid's v_log/v_exp wave-instructions per second of the "
+                              "WHOLE kernel time over the chip's measured transcendental issue rate -- the hard floor of this "
+                              "algorithm (4 transcendentals per node) is that fraction of today's time")
             if pmc:
                 vr["pmc"] = pmc
             line["valu_roofline"] = vr

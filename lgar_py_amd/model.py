@@ -122,8 +122,12 @@ class dpLGAR(nn.Module):
         self.c = self._soil_metrics(te, tr)
         from .autograd import StepTape
         self.tape = StepTape(self)
+        self._latest = None  # ponded_water / ending_volume as of the last forward() (rows 8, 9 of its call_sums)
         self.num_wetting_fronts = self.calc_num_wetting_fronts()
-        z = lambda: self._shape(torch.zeros(N, dtype=torch.float64, device=self.device))
+        # Small models keep the accumulator attributes on the HOST, where the reference keeps them: the agent's loop touches
+        # ~20 of them per forcing row (MassBalance.change_mass), and each touch of a GPU tensor is a kernel launch.
+        self.attr_device = torch.device("cpu") if N <= 64 else self.device
+        z = lambda: self._shape(torch.zeros(N, dtype=torch.float64, device=self.attr_device))
         self.precip, self.PET, self.AET = z(), z(), z()
         self.infiltration, self.runoff, self.giuh_runoff = z(), z(), z()
         self.discharge, self.groundwater_discharge, self.percolation = z(), z(), z()
@@ -173,7 +177,9 @@ class dpLGAR(nn.Module):
         grad_mode = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         want = ("runoff", "percolation") if (series_mode or grad_mode) else ()
         out = self.engine.forward(x[:, :, 0], x[:, :, 1], series=want, check=False, call_sums=True)
-        sums = out["call_sums"].to(torch.float64)  # the 8 accumulators summed over this call's steps, [8+2, N]
+        # the 8 accumulators summed over this call's steps (+ latest ponded_water / ending_volume), [8+2, N]
+        sums = out["call_sums"].to(self.attr_device, torch.float64)
+        self._latest = sums[8:10]
         for j, nm in enumerate(ACC_NAMES[:8]):
             if grad_mode and nm in ("runoff", "percolation"):
                 continue
@@ -182,10 +188,11 @@ class dpLGAR(nn.Module):
         if grad_mode:
             # graph-connected outputs (models/dpLGAR.py:299): this block's per-step runoff / percolation become the
             # outputs of an autograd node whose inputs are the parameters (autograd.StepTape)
-            r_series, p_series = self.tape.record(x, r_series.to(torch.float64), p_series.to(torch.float64))
+            r_series, p_series = self.tape.record(x, r_series.to(self.attr_device, torch.float64),
+                                                  p_series.to(self.attr_device, torch.float64))
             self.runoff = self.runoff + self._shape(r_series.sum(0))
             self.percolation = self.percolation + self._shape(p_series.sum(0))
-        self.previous_precip = self._shape(self.engine.previous_precip.to(torch.float64))
+        self.previous_precip = self._shape((x[-1, :, 0] * float(self.cfg.models.subcycle_length_h)).to(self.attr_device))
         self.groundwater_discharge = self.groundwater_discharge * 0.0
         self.engine.check_status()  # raises ValueError like the reference, after the attributes are up to date
         if series_mode:
@@ -195,11 +202,15 @@ class dpLGAR(nn.Module):
     # state the agent / MassBalance read -----------------------------------------------------------
     @property
     def ponded_water(self):
-        return self._shape(self.engine.ponded_water.to(torch.float64))
+        if self._latest is not None:
+            return self._shape(self._latest[0])
+        return self._shape(self.engine.ponded_water.to(self.attr_device, torch.float64))
 
     @property
     def ending_volume(self):
-        return self._shape(self.engine.ending_volume.to(torch.float64))
+        if self._latest is not None:
+            return self._shape(self._latest[1])
+        return self._shape(self.engine.ending_volume.to(self.attr_device, torch.float64))
 
     @property
     def giuh_runoff_queue(self):
