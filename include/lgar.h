@@ -184,6 +184,8 @@ int32_t lgar_forward_tangent(const LgarDims *dims, const LgarParams *params, con
  * op 4 geff(theta1 = x, theta2 = y)                                        (lgar/green_ampt.py:45-84)
  * op 6 the same trapezoid evaluated operation by operation like the reference (4 pow + sqrt per node, running h)
  * op 5 aet(psi = x, pet = y, dt_h = z)                                      (lgar/aet.py:17-51)
+ * op 7 log2(x), 8 exp2(x) as the Geff trapezoid evaluates them, 9 pow(x, y) as the fast modes evaluate torch.pow
+ *      (accuracy of the device arithmetic on the real hardware; soil parameters unused but required)
  * alpha, n, ksat, theta_e, theta_r: [n] per-item soil parameters. */
 int32_t lgar_leaf_batch(int32_t op, int32_t n_items, const void *x, const void *y, double z, const void *alpha,
                         const void *n, const void *ksat, const void *theta_e, const void *theta_r, int32_t nint,

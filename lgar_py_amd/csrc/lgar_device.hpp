@@ -143,6 +143,11 @@ template <typename S, int NL> struct ColParams {
   S alpha[NL], n[NL], m[NL], inv_m[NL], inv_n[NL], ksat[NL], te[NL], tr[NL], thick[NL], cum[NL];
 };
 
+// c ? a : b on VALUES (a dual number selects component by component: a ternary on two structs can become a select of
+// addresses + a load, which sends the operands through scratch memory)
+__device__ __forceinline__ float choose(bool c, float a, float b) { return c ? a : b; }
+__device__ __forceinline__ double choose(bool c, double a, double b) { return c ? a : b; }
+
 template <typename S, int NL> __device__ __forceinline__ S sel(const S (&a)[NL], int k) {
   // load every element unconditionally, then select on VALUES: a lazily evaluated a[j] becomes a
   // select of addresses + one load, which pins the whole parameter block in scratch memory
@@ -151,7 +156,7 @@ template <typename S, int NL> __device__ __forceinline__ S sel(const S (&a)[NL],
   for (int j = 0; j < NL; j++) v[j] = a[j];
   S r = v[0];
 #pragma unroll
-  for (int j = 1; j < NL; j++) r = (k == j) ? v[j] : r;
+  for (int j = 1; j < NL; j++) r = choose(k == j, v[j], r);
   return r;
 }
 
@@ -292,6 +297,21 @@ template <typename S> __device__ __forceinline__ S geff_fused(const LayerK<S> &l
     }
   }
   int i = 0;
+#ifndef LGAR_NO_FUSED_PAIR
+  // dual numbers run at one wave per SIMD: two nodes per iteration give the scheduler two independent chains (same sums in
+  // the same order)
+  if constexpr (sizeof(S) != sizeof(R) && sizeof(R) == 8) {
+    for (; i + 1 < n_safe; i += 2) {
+      const S hb = h2 + dh;
+      const S ka = node(h2);
+      const S kb = node(hb);
+      g = g + ((k1 + ka) * hdh);
+      g = g + ((ka + kb) * hdh);
+      k1 = kb;
+      h2 = hb + dh;
+    }
+  }
+#endif
   for (; i < n_safe; i++) {
     if (sizeof(R) == 4) h2 = (i + 1 >= nint) ? h_f : h_i + R(i + 1) * dh;
     const S k2 = node(h2);
@@ -302,7 +322,7 @@ template <typename S> __device__ __forceinline__ S geff_fused(const LayerK<S> &l
   for (; i < nint; i++) {
     if (sizeof(R) == 4) h2 = (i + 1 >= nint) ? h_f : h_i + R(i + 1) * dh;
     S k2 = node(h2);
-    k2 = (ab(val(h2)) < R(0.1) || val(h2) < R(0.0)) ? k_sat1 : k2;
+    k2 = choose(ab(val(h2)) < R(0.1) || val(h2) < R(0.0), k_sat1, k2);
     g = g + ((k1 + k2) * hdh);
     k1 = k2;
     if (sizeof(R) != 4) h2 = h2 + dh;
@@ -374,44 +394,59 @@ template <> __device__ __forceinline__ float geff<float>(const LayerK<float> &l,
   }
   const f32x2 dx2 = {dx, dx}, x02 = {x0, x0}, nm12 = {nm1, nm1}, hm2 = {hm, hm};
   const f32x2 one2 = {1.0f, 1.0f}, two2 = {2.0f, 2.0f}, four2 = {4.0f, 4.0f};
-  const f32x2 step2 = two2 * dx2;
-  f32x2 j2 = {1.0f, 2.0f};
+  // A column's result must not depend on which columns share its wavefront (safe_pairs is a property of the wave): node
+  // pair p always sits at x0 + (2p+1, 2p+2) dx (one fma, never a running sum), always goes through the same operations,
+  // and always lands in accumulator p & 1 -- whichever of the three loops below handles it.
+  f32x2 ja = {1.0f, 2.0f}, jb = {3.0f, 4.0f};
   f32x2 acc = {0.0f, 0.0f}, accb = {0.0f, 0.0f};
-  // one node pair: 4 transcendentals + 4 per node-pair ... the packed K_r of two nodes, accumulated by fma
-#define LGAR_GEFF_PAIR(X, ACC)                                                 \
+  // one node pair: 4 transcendentals + 4 packed ops per node-pair -> sqrt(Se) and (1 - P Se)^2 of two nodes
+#define LGAR_GEFF_PAIR(X, SR, TT)                                              \
   {                                                                            \
-    f32x2 lg, P, l1, sr;                                                       \
+    f32x2 lg, P, l1;                                                           \
     lg.x = lg2((X).x); lg.y = lg2((X).y);                                      \
     const f32x2 e0 = nm12 * lg;                                                \
     P.x = ex2(e0.x); P.y = ex2(e0.y);                                          \
     const f32x2 opa = __builtin_elementwise_fma((X), P, one2);                 \
     l1.x = lg2(opa.x); l1.y = lg2(opa.y);                                      \
     const f32x2 e1 = hm2 * l1;                                                 \
-    sr.x = ex2(e1.x); sr.y = ex2(e1.y);                                        \
-    const f32x2 t = __builtin_elementwise_fma(-P, sr * sr, one2);              \
-    (ACC) = __builtin_elementwise_fma(sr, t * t, (ACC));                       \
+    (SR).x = ex2(e1.x); (SR).y = ex2(e1.y);                                    \
+    const f32x2 t = __builtin_elementwise_fma(-P, (SR) * (SR), one2);          \
+    (TT) = t * t;                                                              \
   }
   int it = 0;
-  // four nodes per iteration: two independent chains, one node-counter update
+  // four nodes per iteration: two independent chains
   for (; it + 1 < safe_pairs; it += 2) {
-    const f32x2 xa = __builtin_elementwise_fma(j2, dx2, x02);
-    const f32x2 xb = xa + step2;
-    j2 = j2 + four2;
-    LGAR_GEFF_PAIR(xa, acc)
-    LGAR_GEFF_PAIR(xb, accb)
+    const f32x2 xa = __builtin_elementwise_fma(ja, dx2, x02);
+    const f32x2 xb = __builtin_elementwise_fma(jb, dx2, x02);
+    ja = ja + four2;
+    jb = jb + four2;
+    f32x2 sa, ta, sb, tb;
+    LGAR_GEFF_PAIR(xa, sa, ta)
+    LGAR_GEFF_PAIR(xb, sb, tb)
+    acc = __builtin_elementwise_fma(sa, ta, acc);
+    accb = __builtin_elementwise_fma(sb, tb, accb);
   }
-  for (; it < safe_pairs; it++) {
+  if (it < safe_pairs) {  // `it` is even here
+    const f32x2 x = __builtin_elementwise_fma(ja, dx2, x02);
+    f32x2 sr, tt;
+    LGAR_GEFF_PAIR(x, sr, tt)
+    acc = __builtin_elementwise_fma(sr, tt, acc);
+    it++;
+  }
+  for (; it < pairs; it++) {  // nodes that may fall under the |h| < 0.1 cut: K_r = ksat1 there
+    const float j0 = float(2 * it + 1);
+    const f32x2 j2 = {j0, j0 + 1.0f};
     const f32x2 x = __builtin_elementwise_fma(j2, dx2, x02);
-    j2 = j2 + two2;
-    LGAR_GEFF_PAIR(x, acc)
+    f32x2 sr, tt;
+    LGAR_GEFF_PAIR(x, sr, tt)
+    sr.x = (x.x < xcut) ? ksat1 : sr.x;
+    tt.x = (x.x < xcut) ? 1.0f : tt.x;
+    sr.y = (x.y < xcut) ? ksat1 : sr.y;
+    tt.y = (x.y < xcut) ? 1.0f : tt.y;
+    if (it & 1) accb = __builtin_elementwise_fma(sr, tt, accb);
+    else acc = __builtin_elementwise_fma(sr, tt, acc);
   }
 #undef LGAR_GEFF_PAIR
-  for (; it < pairs; it++) {
-    const f32x2 x = __builtin_elementwise_fma(j2, dx2, x02);
-    j2 = j2 + two2;
-    acc.x += node(x.x);
-    acc.y += node(x.y);
-  }
   acc = acc + accb;
   float sum = acc.x + acc.y;
   if (M & 1) sum += node(__builtin_fmaf(float(M), dx, x0));
@@ -535,7 +570,11 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
 #endif
     // one lane per wave-level evaluation adds 1 above the fault bits (no register, no LDS word; summed over the wave at the
     // end of the block): bits 8..31 of status are otherwise unused while a column is integrated
+#ifdef LGAR_COUNT_LANES  // measurement variant (tools/ablate.py): every evaluating lane counts
+    if (count_geff) status += (1 << LGAR_ST_STEP_SHIFT);
+#else
     if (count_geff && first_active_lane()) status += (1 << LGAR_ST_STEP_SHIFT);
+#endif
 #ifdef LGAR_DUP_GEFF
     if constexpr (sizeof(S) == sizeof(R)) {
       const S extra = geff(lk, opaque(theta1), opaque(theta2), G->nint);
@@ -553,7 +592,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
 #pragma unroll
     for (int j = 0; j < NL - 1; j++) {
       const S cj = P.cum[j];
-      r = (k == j + 1) ? cj : r;
+      r = choose(k == j + 1, cj, r);
     }
     return r;
   }

@@ -20,6 +20,9 @@ template <typename R> struct Dual {
 template <typename R> struct Real<Dual<R>> { using type = R; };
 
 template <typename R> __device__ __forceinline__ R val(const Dual<R> &x) { return x.v; }
+template <typename R> __device__ __forceinline__ Dual<R> choose(bool c, const Dual<R> &a, const Dual<R> &b) {
+  return Dual<R>(c ? a.v : b.v, c ? a.d : b.d);
+}
 
 #define LGAR_DUAL_BIN(OP, VEXPR, DEXPR_DD, DEXPR_DR, DEXPR_RD)                                                          \
   template <typename R> __device__ __forceinline__ Dual<R> operator OP(const Dual<R> &a, const Dual<R> &b) {            \
@@ -87,8 +90,14 @@ template <typename R> __device__ __forceinline__ Dual<R> ex2(const Dual<R> &y) {
   const R v = ex2(y.v);
   return Dual<R>(v, v * R(0.6931471805599453) * y.d);
 }
-template <typename R> __device__ __forceinline__ Dual<R> lg2p(const Dual<R> &x) { return lg2(x); }
-template <typename R> __device__ __forceinline__ Dual<R> ex2p(const Dual<R> &y) { return ex2(y); }
+// inside the Geff trapezoid (x > 0, y finite): the select-free cores, and the tangent's 1/x by reciprocal + Newton
+template <typename R> __device__ __forceinline__ Dual<R> lg2p(const Dual<R> &x) {
+  return Dual<R>(lg2p(x.v), x.d * (fast_recip(x.v) * R(1.4426950408889634)));
+}
+template <typename R> __device__ __forceinline__ Dual<R> ex2p(const Dual<R> &y) {
+  const R v = ex2p(y.v);
+  return Dual<R>(v, v * R(0.6931471805599453) * y.d);
+}
 #ifndef LGAR_NO_FUSED_GEFF
 template <> __device__ __forceinline__ Dual<double> geff<Dual<double>>(const LayerK<Dual<double>> &l, Dual<double> t1,
                                                                        Dual<double> t2, int nint) {

@@ -39,6 +39,9 @@ template <typename R> __global__ void lgar_leaf_kernel(LeafArgs<R> a) {
     case 4: r = geff(l, x, y, a.nint); break;
     case 5: r = aet_fn(l, y, a.z, x, a.wp_psi); break;
     case 6: r = geff_literal<R, (sizeof(R) == 8) ? 1 : 0>(l, x, y, a.nint); break;
+    case 7: r = lg2p(x); break;
+    case 8: r = ex2p(x); break;
+    case 9: r = pw(x, y); break;
   }
   a.out[i] = r;
 }
@@ -117,7 +120,7 @@ int32_t lgar_forward_tangent(const LgarDims *dims, const LgarParams *params, con
 int32_t lgar_leaf_batch(int32_t op, int32_t n_items, const void *x, const void *y, double z, const void *alpha,
                         const void *n, const void *ksat, const void *theta_e, const void *theta_r, int32_t nint,
                         double wilting_point_psi, void *out, int32_t dtype, void *stream) {
-  if (op < 0 || op > 6 || n_items <= 0 || !x || !alpha || !n || !ksat || !theta_e || !theta_r || !out) return LGAR_E_ARG;
+  if (op < 0 || op > 9 || n_items <= 0 || !x || !alpha || !n || !ksat || !theta_e || !theta_r || !out) return LGAR_E_ARG;
   if ((op == 4 || op == 5 || op == 6) && !y) return LGAR_E_ARG;
   const unsigned grid = (unsigned)((n_items + 255) / 256);
   hipStream_t st = (hipStream_t)stream;

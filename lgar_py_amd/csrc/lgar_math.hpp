@@ -85,6 +85,20 @@ __device__ __forceinline__ double fast_log2(double x) {
   return r;
 }
 
+// 1/x for finite non-zero x to ~1 ulp: v_rcp_f64 + two Newton steps (the IEEE divide is ~2x the instructions); used where a
+// quotient feeds a DERIVATIVE (dual numbers), never where the reference's own rounding matters
+__device__ __forceinline__ double fast_recip(double x) {
+#ifndef LGAR_DEVSIM
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+#else
+  return 1.0 / x;
+#endif
+}
+__device__ __forceinline__ float fast_recip(float x) { return 1.0f / x; }
+
 __device__ __forceinline__ double fast_pow(double x, double y) { return fast_exp2(y * fast_log2(x)); }
 
 }  // namespace lgar

@@ -443,6 +443,31 @@ CASES["six_layer_phil_300"] = (run_case, dict(forcing=PH, soil=SIX, pdm=2, subcy
 CASES["grad_six_layer_synth1"] = (run_case, dict(forcing="forcing_data_synth_1.txt", soil=SIX, pdm=0.0, subcycle_s=300, forcing_res_s=300, endtime_h=12.0, grad=True))
 
 
+def bench_member(col, n_columns=16384):
+    """Soil and forcing multiplier of column `col` of the benchmark ensemble (lgar_py_amd/workloads.py perturbed_columns
+    seed 0 / forcing_scale seed 1000, restated so this script does not import the package under test)."""
+    rng = np.random.default_rng(0)
+    out = dict(thickness=list(PHIL["thickness"]))
+    for k in ["alpha", "n", "ksat", "theta_e", "theta_r"]:
+        b = np.asarray(PHIL[k], dtype=np.float64)[:, None]
+        out[k] = [float(v) for v in (b * (1.0 + 0.10 * (2.0 * rng.random((3, n_columns)) - 1.0)))[:, col]]
+    scale = float((0.5 + rng_scale(n_columns))[col])
+    return out, scale
+
+
+def rng_scale(n_columns):
+    return np.random.default_rng(1000).random(n_columns)
+
+
+# Members of the benchmark ensemble in which the reference's own update drops one step's infiltration (top layer saturated,
+# front advancing in layer 2: the column's water volume does not grow by the infiltration it reports, ~0.1 cm in one step):
+# pinned here so that the oracle's and the kernels' identical behaviour is the reference's, not a shared mistake.
+for col in (15731, 10707):
+    soil_, scale_ = bench_member(col)
+    CASES["bench_col%d" % col] = (run_case, dict(forcing="forcing_data_synth_1.txt", soil=soil_, pdm=0.0, subcycle_s=300,
+                                                  forcing_res_s=300, endtime_h=12.0, forcing_scale=scale_))
+
+
 def _run(name):
     fn, kw = CASES[name]
     try:

@@ -28,6 +28,8 @@ VARIANTS = {
     "nogeff_noepi": ["-DLGAR_ABL_NOGEFF", "-DLGAR_ABL_NOEPILOGUE"],
     "skeleton": ["-DLGAR_ABL_NOGEFF", "-DLGAR_ABL_NODZDT", "-DLGAR_ABL_NOMOVE", "-DLGAR_ABL_NOINSERT", "-DLGAR_ABL_NOEPILOGUE"],
     "contract": ["-ffp-contract=fast"],
+    "count_lanes": ["-DLGAR_COUNT_LANES"],  # geff_calls then counts LANE-level evaluations (base: wave-level)
+    "tan_nopair": ["-DLGAR_NO_FUSED_PAIR"],  # dual-number Geff one node per iteration (run tools/bench_autograd.py on it)
     "occ3": ["-DLGAR_OCC_F32_SMALL=3"],
     "occ2": ["-DLGAR_OCC_F32_SMALL=2"],
     "occ1_f64": ["-DLGAR_OCC_F64_SMALL=1"],
@@ -60,7 +62,7 @@ for rep in range(%(reps)d):
 ms = sorted(ms[1:])
 print(json.dumps(dict(variant=%(name)r, dtype=%(dt)r, columns=N, ms_median=ms[len(ms) // 2], ms_min=ms[0],
                       col_steps_per_s=N * T / (ms[len(ms) // 2] * 1e-3), faulted=int((eng.status != 0).sum()),
-                      runoff_sum=float(out["runoff"].double().sum()))))
+                      geff_calls=int(eng.geff_wave_calls()), runoff_sum=float(out["runoff"].double().sum()))))
 """
 
 
@@ -70,7 +72,7 @@ def main():
     names = [v for v in os.environ.get("LGAR_VARIANTS", "").split(",") if v] or list(VARIANTS)
     if what == "build":
         for nm in names:
-            print(nm, B.build_variant(nm, VARIANTS[nm]), flush=True)
+            print(nm, B.build_variant(nm, VARIANTS[nm], tangent=nm.startswith("tan_")), flush=True)
         return
     dt = sys.argv[2] if len(sys.argv) > 2 else "f32"
     n = int(sys.argv[3]) if len(sys.argv) > 3 else 1 << 20
