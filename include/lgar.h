@@ -96,7 +96,10 @@ typedef struct {
                                 (Nf = 1: one basin series for every column, the reference's Data yields exactly that,
                                 data/Data.py:32-37; the differentiable path lays its parameter directions side by side this
                                 way without replicating the forcing) */
-  int32_t reserved2;
+  int32_t forcing_group;     /* 0 or 1: as above.  G > 1: G CONSECUTIVE soil columns share a forcing column -- column c reads
+                                forcing column (c / G) % forcing_columns; n_columns must be a multiple of G * forcing_columns.
+                                (The differentiable path puts the G parameter directions of one column in adjacent lanes:
+                                they take the same branches, so a wavefront diverges over 64 / G columns instead of 64.) */
 } LgarDims;
 
 /* Per-column soil parameters, each [n_layers][n_columns].  Replaces dpLGAR.alpha/.n/.ksat

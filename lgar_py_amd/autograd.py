@@ -48,7 +48,9 @@ def parameter_vjp(eng, precip, pet, w_runoff, w_perc, wanted, check=True):
             out[(kind, l)], _, st = eng.tangent({kind: dmat}, precip, pet, w_runoff=w_runoff, w_perc=w_perc)
             status |= st
             continue
-        rep = lambda t: t.repeat(1, Dg)
+        # column n's Dg directions sit in ADJACENT lanes (column n * Dg + b): they follow the same branches, so a wavefront
+        # diverges over 64 / Dg columns instead of 64; the kernel reads forcing / weight column c // Dg (forcing_group)
+        rep = lambda t: t.repeat_interleave(Dg, dim=1)
         big = LgarEngine(rep(eng.alpha), rep(eng.n), rep(eng.ksat), rep(eng.theta_e), rep(eng.theta_r), rep(eng.thickness),
                          dt_h=d.dt_h, num_subcycles=d.num_subcycles, initial_psi=d.initial_psi,
                          ponded_depth_max=d.ponded_depth_max, wilting_point_psi=d.wilting_point_psi,
@@ -58,11 +60,11 @@ def parameter_vjp(eng, precip, pet, w_runoff, w_perc, wanted, check=True):
                          with_state=False)
         dirs = {k: torch.zeros(L, Dg * N, dtype=eng.dtype, device=eng.device) for k in KINDS}
         for b, (kind, l) in enumerate(part):
-            dirs[kind][l, b * N:(b + 1) * N] = 1.0
-        g, _, st = big.tangent(dirs, precip, pet, w_runoff=w_runoff, w_perc=w_perc)  # forcing / weights broadcast by the kernel
+            dirs[kind][l, b::Dg] = 1.0
+        g, _, st = big.tangent(dirs, precip, pet, w_runoff=w_runoff, w_perc=w_perc, forcing_group=Dg)  # forcing / weights broadcast by the kernel
         for b, key in enumerate(part):
-            out[key] = g[b * N:(b + 1) * N]
-            status |= st[b * N:(b + 1) * N]
+            out[key] = g[b::Dg].contiguous()
+            status |= st[b::Dg]
     status &= ST_FAULT_MASK
     bad = status != 0
     if bool(bad.any()):

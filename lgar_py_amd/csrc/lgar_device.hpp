@@ -261,6 +261,17 @@ template <typename S> __device__ __forceinline__ S geff(const LayerK<S> &l, S th
 // (h_i + (i+1) dh, last node = h_f): its running sum drifts by ~nint ulps of h_i, cm-scale for very dry soil, and the last
 // trapezoid dominates the integral.  The plain-float kernels use the packed loop further down instead.
 #ifndef LGAR_NO_FUSED_GEFF
+// K(h) of one trapezoid node, fused (see above); nm1 = n - 1, half_m = -m/2.  lgar_dual.hpp overloads it for dual numbers
+// (same value operations, hand-derived tangent).
+template <typename S> __device__ __forceinline__ S geff_node(const LayerK<S> &l, const S &nm1, const S &half_m, const S &h) {
+  using R = real_t<S>;
+  const S x = l.alpha * h;
+  const S P = ex2p(nm1 * lg2p(x));
+  const S l1 = lg2p(R(1.0) + x * P);
+  const S sqrt_se = ex2p(half_m * l1);
+  const S t = R(1.0) - P * (sqrt_se * sqrt_se);
+  return l.ksat * sqrt_se * (t * t);
+}
 template <typename S> __device__ __forceinline__ S geff_fused(const LayerK<S> &l, S theta1, S theta2, int nint) {
   using R = real_t<S>;
   const S se_i = se_from_theta(l, theta1);
@@ -276,14 +287,7 @@ template <typename S> __device__ __forceinline__ S geff_fused(const LayerK<S> &l
   S k1 = k_from_se(l, se_i);
   S h2 = h_i + dh;
   // four transcendentals per node: P = a^m = x^(n-1), a = x P, sqrt(Se) = (1+a)^(-m/2), (a/(1+a))^m = P Se
-  auto node = [&](const S &h) {
-    const S x = l.alpha * h;
-    const S P = ex2p(nm1 * lg2p(x));
-    const S l1 = lg2p(R(1.0) + x * P);
-    const S sqrt_se = ex2p(half_m * l1);
-    const S t = R(1.0) - P * (sqrt_se * sqrt_se);
-    return l.ksat * sqrt_se * (t * t);
-  };
+  auto node = [&](const S &h) { return geff_node(l, nm1, half_m, h); };
   // The |h| < 0.1 -> Se = 1 rule (utils.py:124-128) can only bind on a SUFFIX of the nodes (h falls monotonically from
   // h_i to h_f): a wave-uniform count of leading nodes that no lane needs to test runs select-free.
   const R jf = (val(h_i) - R(0.1)) / -val(dh) - R(2.0);

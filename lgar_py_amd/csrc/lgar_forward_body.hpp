@@ -17,7 +17,7 @@ namespace lgar {
 
 template <typename R> struct KArgs {
   int N, T, F;                                            // columns, forcing steps, rows of the per-front state arrays
-  int Nf;                                                 // forcing columns (N, or a divisor of N: broadcast c % Nf)
+  int Nf, Fg;                                             // forcing columns and group: column c reads forcing column (c / Fg) % Nf
   unsigned *ticket;                                       // null, or the work counter of this launch (persistent waves)
   int chain_first, chain_last;                            // position in the capacity chain (see above)
   const R *alpha, *n, *ksat, *theta_e, *theta_r, *thick;  // [NL][N]
@@ -221,7 +221,7 @@ __device__ __forceinline__ void forward_lane(const LGAR_KARG KArgs<R> *ap, size_
   // forcing is covered by the other three waves of the SIMD.)
   const int T = a.T;
   const size_t Nf = (size_t)a.Nf;
-  const size_t cf = (Nf == N) ? c : c % Nf;  // this column's forcing column
+  const size_t cf = (Nf == N) ? c : (c / (size_t)a.Fg) % Nf;  // this column's forcing column
   for (int t = 0; t < T; t++) {
     ap = launder(ap);
     const LGAR_KARG KArgs<R> &a = *ap;  // (shadows the outer reference on purpose)

@@ -26,7 +26,10 @@ template <typename R> inline Glob<R> make_glob(const LgarDims *d) {
 }
 
 inline int front_slots(const LgarDims *d) { return d->front_slots > 0 ? d->front_slots : LGAR_FMAX; }
-inline int forcing_columns(const LgarDims *d) { return d->forcing_columns > 0 ? d->forcing_columns : d->n_columns; }
+inline int forcing_group(const LgarDims *d) { return d->forcing_group > 1 ? d->forcing_group : 1; }
+inline int forcing_columns(const LgarDims *d) {
+  return d->forcing_columns > 0 ? d->forcing_columns : d->n_columns / forcing_group(d);
+}
 
 inline int check_dims(const LgarDims *d) {
   if (!d) return LGAR_E_ARG;
@@ -35,7 +38,8 @@ inline int check_dims(const LgarDims *d) {
   if (d->nint <= 0 || d->num_subcycles <= 0 || d->n_steps < 0 || d->n_steps >= (1 << 23)) return LGAR_E_ARG;
   if (d->search_mode < 0 || d->search_mode > 2) return LGAR_E_ARG;
   if (d->front_slots < 0 || d->front_slots > LGAR_FMAX || (d->front_slots > 0 && d->front_slots < d->n_layers + 1)) return LGAR_E_ARG;
-  if (d->forcing_columns < 0 || (d->forcing_columns > 0 && d->n_columns % d->forcing_columns != 0)) return LGAR_E_ARG;
+  if (d->forcing_columns < 0 || d->forcing_group < 0 || d->n_columns % forcing_group(d) != 0) return LGAR_E_ARG;
+  if (d->forcing_columns > 0 && (d->n_columns / forcing_group(d)) % d->forcing_columns != 0) return LGAR_E_ARG;
   if (!(d->dt_h > 0.0)) return LGAR_E_ARG;
   return 0;
 }

@@ -77,6 +77,7 @@ static KArgs<R> make_args(const LgarDims *d, const LgarParams *p, LgarState *s, 
   a.T = d->n_steps;
   a.F = front_slots(d);
   a.Nf = forcing_columns(d);
+  a.Fg = forcing_group(d);
   a.ticket = nullptr;
   a.chain_first = a.chain_last = 1;
   a.alpha = (const R *)p->alpha; a.n = (const R *)p->n; a.ksat = (const R *)p->ksat;

@@ -16,7 +16,7 @@
 namespace lgar {
 
 template <typename R> struct TArgs {
-  int N, T, Nf;  // Nf: columns of the forcing and weight arrays (N, or a divisor of N: broadcast c % Nf)
+  int N, T, Nf, Fg;  // Nf, Fg: columns of the forcing and weight arrays and group: column c reads column (c / Fg) % Nf
   int chain_first, chain_last;
   const R *alpha, *n, *ksat, *theta_e, *theta_r, *thick;  // [NL][N]
   const R *d_alpha, *d_n, *d_ksat;                        // [NL][N] or null
@@ -58,7 +58,7 @@ __device__ __forceinline__ void tangent_lane(const LGAR_KARG TArgs<R> *ap, size_
   R grad = R(0);
   bool handed_over = false;
   const size_t Nf = (size_t)a.Nf;
-  const size_t cf = (Nf == N) ? c : c % Nf;
+  const size_t cf = (Nf == N) ? c : (c / (size_t)a.Fg) % Nf;
   for (int t = 0; t < a.T; t++) {
     const size_t o = (size_t)t * Nf + cf;
     if (!a.chain_last && col.nf + a.G.nsub > FMAX) {

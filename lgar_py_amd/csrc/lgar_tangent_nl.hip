@@ -30,7 +30,7 @@ static int tangent_typed(const LgarDims *dims, const LgarParams *params, const L
                          const void *w_runoff, const void *w_perc, void *grad_out, void *tangent_runoff, int32_t *status,
                          hipStream_t st) {
   const unsigned grid = (unsigned)((dims->n_columns + WAVE - 1) / WAVE);
-  TArgs<R> a{dims->n_columns, dims->n_steps, forcing_columns(dims), 1, 1, (const R *)params->alpha, (const R *)params->n, (const R *)params->ksat,
+  TArgs<R> a{dims->n_columns, dims->n_steps, forcing_columns(dims), forcing_group(dims), 1, 1, (const R *)params->alpha, (const R *)params->n, (const R *)params->ksat,
              (const R *)params->theta_e, (const R *)params->theta_r, (const R *)params->thickness,
              (const R *)direction->alpha, (const R *)direction->n, (const R *)direction->ksat,
              (const R *)forcing->precip, (const R *)forcing->pet, (const R *)w_runoff, (const R *)w_perc,

@@ -125,10 +125,21 @@ class LgarEngine:
                                           self.status.data_ptr(), self._dt, self._stream())
         _capi.check(rc, "lgar_state_init")
 
+    def _set_forcing_layout(self, precip, pet, forcing_group):
+        g = max(1, int(forcing_group))
+        if (precip.shape != pet.shape or precip.dim() != 2 or precip.shape[1] < 1 or self.N % g != 0
+                or (self.N // g) % precip.shape[1] != 0):
+            raise LgarError("forcing must be [T, %d] (or [T, Nf] with forcing_group * Nf dividing it: column c reads forcing "
+                            "column (c // forcing_group) %% Nf); got %s / %s, forcing_group %d"
+                            % (self.N, tuple(precip.shape), tuple(pet.shape), g))
+        self.dims.forcing_columns = precip.shape[1]
+        self.dims.forcing_group = g
+
     def forward(self, precip, pet, series=("runoff", "percolation"), out=None, check=True, basin=(), weights=None,
-                call_sums=False):
+                call_sums=False, forcing_group=1):
         """Advance every column by T forcing steps.  precip/pet: [T, N] cm/h on self.device, or [T, Nf] with Nf dividing N
-        (broadcast: column c reads forcing column c % Nf; Nf = 1 is one basin series for every column).
+        (broadcast: column c reads forcing column c % Nf; Nf = 1 is one basin series for every column); with forcing_group
+        G > 1, G consecutive columns share a forcing column: column c reads (c // G) % Nf.
 
         Returns {name: tensor[T, N]} for the requested per-step series (the model accumulators as they
         stand after each forward(), before MassBalance.change_mass zeroes them).  basin: names whose per-step sum over
@@ -141,11 +152,8 @@ class LgarEngine:
         pet = torch.as_tensor(pet).to(self.device, self.dtype).contiguous()
         if precip.dim() == 1:
             precip, pet = precip[None, :], pet[None, :]
-        if precip.shape != pet.shape or precip.dim() != 2 or precip.shape[1] < 1 or self.N % precip.shape[1] != 0:
-            raise LgarError("forcing must be [T, %d] (or [T, Nf] with Nf dividing it: column c reads forcing column c %% Nf); "
-                            "got %s / %s" % (self.N, tuple(precip.shape), tuple(pet.shape)))
+        self._set_forcing_layout(precip, pet, forcing_group)
         T = precip.shape[0]
-        self.dims.forcing_columns = precip.shape[1]
         res = {}
         so = _capi.LgarStepOut()
         for nm in series:
@@ -182,24 +190,22 @@ class LgarEngine:
             self.check_status()
         return res
 
-    def tangent(self, direction, precip, pet, w_runoff=None, w_perc=None, want_series=False):
+    def tangent(self, direction, precip, pet, w_runoff=None, w_perc=None, want_series=False, forcing_group=1):
         """Forward-mode tangent from a FRESH state (set_internal_states) over the whole forcing series.
 
         direction: {"alpha" | "n" | "ksat": [L, N] tensor} -- the parameter perturbation (missing = 0).
-        precip / pet / w_runoff / w_perc: [T, N], or all [T, Nf] with Nf dividing N (column c uses column c % Nf of each).
+        precip / pet / w_runoff / w_perc: [T, N], or all [T, Nf] with forcing_group * Nf dividing N (column c uses column
+        (c // forcing_group) % Nf of each).
         Returns (grad[N], tangent_runoff[T, N] or None, status[N]) with
         grad[c] = sum_t w_runoff[t, c] * d runoff_t[c] + w_perc[t, c] * d percolation_t[c].  status != 0 marks columns whose
         tangent integration faulted (their grad entry is not a gradient): callers must check it (autograd.parameter_vjp does)."""
         prep = lambda t: None if t is None else torch.as_tensor(t).to(self.device, self.dtype).contiguous()
         precip, pet, w_runoff, w_perc = prep(precip), prep(pet), prep(w_runoff), prep(w_perc)
-        if precip.dim() != 2 or precip.shape[1] < 1 or self.N % precip.shape[1] != 0 or pet.shape != precip.shape:
-            raise LgarError("forcing must be [T, %d] or [T, Nf] with Nf dividing it; got %s / %s"
-                            % (self.N, tuple(precip.shape), tuple(pet.shape)))
+        self._set_forcing_layout(precip, pet, forcing_group)
         for nm, w in (("w_runoff", w_runoff), ("w_perc", w_perc)):
             if w is not None and w.shape != precip.shape:
                 raise LgarError("%s must be [T, N] like the forcing; got %s" % (nm, tuple(w.shape)))
         T = precip.shape[0]
-        self.dims.forcing_columns = precip.shape[1]
         dirs = {k: prep(direction.get(k)) for k in ("alpha", "n", "ksat")}
         for k, v in dirs.items():
             if v is not None and tuple(v.shape) != (self.L, self.N):

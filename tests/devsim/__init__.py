@@ -25,7 +25,7 @@ class LgarDims(C.Structure):
                 ("search_mode", C.c_int32), ("bottom_mode", C.c_int32), ("use_closed_form_G", C.c_int32), ("front_slots", C.c_int32),
                 ("dt_h", C.c_double), ("initial_psi", C.c_double), ("ponded_depth_max", C.c_double),
                 ("wilting_point_psi", C.c_double), ("frozen_factor", C.c_double), ("giuh", C.c_double * GMAX),
-                ("iter_cap", C.c_int64), ("forcing_columns", C.c_int32), ("reserved2", C.c_int32)]
+                ("iter_cap", C.c_int64), ("forcing_columns", C.c_int32), ("forcing_group", C.c_int32)]
 
 
 class LgarParams(C.Structure):
@@ -125,12 +125,13 @@ class SimEngine:
                                         self.status.ctypes.data_as(C.c_void_p), self._dt)
         assert rc == 0, rc
 
-    def forward(self, precip, pet, series=("runoff", "percolation"), basin=(), weights=None, call_sums=False):
+    def forward(self, precip, pet, series=("runoff", "percolation"), basin=(), weights=None, call_sums=False, forcing_group=1):
         precip = np.ascontiguousarray(np.asarray(precip, dtype=np.float64).astype(self.dtype))
         pet = np.ascontiguousarray(np.asarray(pet, dtype=np.float64).astype(self.dtype))
         T = precip.shape[0]
-        assert precip.shape == pet.shape and self.N % precip.shape[1] == 0
+        assert precip.shape == pet.shape and self.N % (precip.shape[1] * forcing_group) == 0
         self.dims.forcing_columns = precip.shape[1]
+        self.dims.forcing_group = forcing_group
         res, so = {}, LgarStepOut()
         for nm in series:
             buf = np.zeros((T, self.N), dtype=self.dtype)
@@ -158,12 +159,13 @@ class SimEngine:
         assert rc == 0, rc
         return res
 
-    def tangent(self, direction, precip, pet, w_runoff=None, w_perc=None, want_series=False):
+    def tangent(self, direction, precip, pet, w_runoff=None, w_perc=None, want_series=False, forcing_group=1):
         prep = lambda t: None if t is None else np.ascontiguousarray(np.asarray(t, dtype=np.float64).astype(self.dtype))
         precip, pet, w_runoff, w_perc = prep(precip), prep(pet), prep(w_runoff), prep(w_perc)
         T = precip.shape[0]
-        assert self.N % precip.shape[1] == 0
+        assert self.N % (precip.shape[1] * forcing_group) == 0
         self.dims.forcing_columns = precip.shape[1]
+        self.dims.forcing_group = forcing_group
         dirs = {k: prep(direction.get(k)) for k in ("alpha", "n", "ksat")}
         ptr = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
         dstruct = LgarParams(ptr(dirs["alpha"]), ptr(dirs["n"]), ptr(dirs["ksat"]), None, None, None)

@@ -38,7 +38,8 @@ template <typename R>
 KArgs<R> make_args(const LgarDims *d, const LgarParams *p, LgarState *s, const LgarForcing *f, const LgarStepOut *o, int32_t *status) {
   KArgs<R> a;
   a.N = d->n_columns; a.T = d->n_steps; a.F = d->front_slots > 0 ? d->front_slots : LGAR_FMAX;
-  a.Nf = d->forcing_columns > 0 ? d->forcing_columns : d->n_columns;
+  a.Fg = d->forcing_group > 1 ? d->forcing_group : 1;
+  a.Nf = d->forcing_columns > 0 ? d->forcing_columns : d->n_columns / a.Fg;
   a.chain_first = a.chain_last = 1;
   a.ticket = nullptr;
   a.alpha = (const R *)p->alpha; a.n = (const R *)p->n; a.ksat = (const R *)p->ksat;
@@ -94,7 +95,8 @@ template <typename R, int NL, int CAP, int MODE> void run_tangent(const TArgs<R>
 template <typename R, int NL>
 int tangent_typed(const LgarDims *d, const LgarParams *p, const LgarParams *dir, const LgarForcing *f, const void *wr, const void *wp,
                   void *grad, void *tser, int32_t *status) {
-  TArgs<R> a{d->n_columns, d->n_steps, d->forcing_columns > 0 ? d->forcing_columns : d->n_columns, 1, 1, (const R *)p->alpha, (const R *)p->n, (const R *)p->ksat, (const R *)p->theta_e,
+  TArgs<R> a{d->n_columns, d->n_steps, d->forcing_columns > 0 ? d->forcing_columns : d->n_columns / (d->forcing_group > 1 ? d->forcing_group : 1),
+             d->forcing_group > 1 ? d->forcing_group : 1, 1, 1, (const R *)p->alpha, (const R *)p->n, (const R *)p->ksat, (const R *)p->theta_e,
              (const R *)p->theta_r, (const R *)p->thickness, (const R *)dir->alpha, (const R *)dir->n, (const R *)dir->ksat,
              (const R *)f->precip, (const R *)f->pet, (const R *)wr, (const R *)wp, (R *)grad, (R *)tser, status, make_glob<R>(d)};
   if (d->search_mode == 0) { run_tangent<R, NL, LGAR_FMAX, 0>(a); return 0; }

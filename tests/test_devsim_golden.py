@@ -253,3 +253,12 @@ def test_forcing_broadcast_equals_replicated_forcing():
     g1, _, s1 = c.tangent({"ksat": dirs}, pr3, pe3, w_runoff=w)
     g2, _, s2 = d.tangent({"ksat": dirs}, np.tile(pr3, (1, 2)), np.tile(pe3, (1, 2)), w_runoff=np.tile(w, (1, 2)))
     assert np.array_equal(g1, g2) and (s1 == 0).all() and np.abs(g1).max() > 0
+    # forcing_group: G consecutive columns share a forcing column (the differentiable path's interleaved directions)
+    e = _engine(g, N)
+    grp = e.forward(pr3, pe3, series=("runoff",), forcing_group=2)  # columns (0,1), (2,3), (4,5) see forcing columns 0, 1, 2
+    assert np.array_equal(grp["runoff"], rep["runoff"][:, [0, 3, 1, 4, 2, 5]])
+    dirs2 = np.zeros((3, N))
+    dirs2[0, 0::2] = 1.0
+    dirs2[1, 1::2] = 1.0
+    g3, _, s3 = e.tangent({"ksat": dirs2}, pr3, pe3, w_runoff=w, forcing_group=2)
+    assert np.array_equal(g3, g2[[0, 3, 1, 4, 2, 5]]) and (s3 == 0).all()

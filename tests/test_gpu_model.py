@@ -210,3 +210,13 @@ def test_forcing_broadcast_on_gpu():
     assert float((one["AET"][:, 7] - ref).abs().max()) <= 1e-6 * float(ref.abs().max())
     with pytest.raises(lg.LgarError, match="dividing"):
         b.forward(f[:, 0:1].expand(-1, 3).contiguous(), f[:, 1:2].expand(-1, 3).contiguous())
+    # forcing_group: G consecutive columns share a forcing column
+    sc = torch.linspace(0.5, 1.5, 50, dtype=torch.float64)
+    pr, pe = f[:, 0:1] * sc[None, :], f[:, 1:2].expand(-1, 50).contiguous()
+    c = lg.LgarEngine(g["alpha"], g["n"], g["ksat"], g["theta_e"], g["theta_r"], g["thickness"], **kw)
+    grp = c.forward(pr, pe, series=("runoff",), forcing_group=4)["runoff"]
+    d = lg.LgarEngine(g["alpha"], g["n"], g["ksat"], g["theta_e"], g["theta_r"], g["thickness"], **kw)
+    rep = d.forward(pr.repeat_interleave(4, dim=1), pe.repeat_interleave(4, dim=1), series=("runoff",))["runoff"]
+    assert torch.equal(grp, rep)
+    with pytest.raises(lg.LgarError, match="dividing"):
+        c.forward(pr, pe, forcing_group=3)
