@@ -1057,6 +1057,10 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
             if (lq < lj) {  // quirk: EVERY front of all shallower layers is overwritten (Layer.py:1117-1143)
               const LayerK<S> lql = pick(P, lq);
               F.PS(q) = h_from_se<S, POL>(lql, se_from_theta(lql, dry_th));
+              // another layer's theta can exceed this layer's theta_e: Se > 1, a negative pow base, and the reference
+              // raises (utils.py:25-27) -- but the NaN psi is overwritten by update_psi before anything reads it, so it
+              // must be caught here
+              if (is_nan(val(F.PS(q)))) status |= LGAR_ST_NEGBASE;
               F.TH(q) = theta_from_h<S, POL>(lql, dry_ps);
             }
           }
@@ -1065,7 +1069,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
       S after = mass_balance();
       S mc = ab(after - before);
 #pragma unroll
-      for (int j = 0; j < NL; j++) ls[j] = (k == j) ? (ls[j] + mc) : ls[j];
+      for (int j = 0; j < NL; j++) ls[j] = choose(k == j, ls[j] + mc, ls[j]);
       // this layer is done: continue with the first front of the next layer
       while (i < nf && F.layer(i) == k) i++;
     }

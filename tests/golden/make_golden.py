@@ -167,7 +167,8 @@ def pulse_forcing(T, a0, decay, gap):
 
 
 def run_case(name, forcing, soil, pdm, subcycle_s, forcing_res_s, endtime_h, forcing_scale=1.0, grad=False,
-             record_fronts=True, initial_psi=2000.0, closed_form=False, frozen_factor=1, pulse=None, frec=FREC):
+             record_fronts=True, initial_psi=2000.0, closed_form=False, frozen_factor=1, pulse=None, frec=FREC,
+             scale_pet=True):
     FREC = frec
     torch.set_default_dtype(torch.float64)
     torch.manual_seed(0)
@@ -180,6 +181,9 @@ def run_case(name, forcing, soil, pdm, subcycle_s, forcing_res_s, endtime_h, for
     cfg = build_cfg(fcsv, sdat, soil, pdm, subcycle_s, forcing_res_s, endtime_h, initial_psi, closed_form, frozen_factor)
     data = Data(cfg)
     x = data.x * forcing_scale
+    if not scale_pet:  # multiplier on the precipitation column only
+        x = data.x.clone()
+        x[:, 0] = x[:, 0] * forcing_scale
     T = x.shape[0]
     if pulse is not None:  # programmatic forcing (cm/h) in place of the file's values; the file only sets T
         x = torch.tensor(pulse_forcing(T, **pulse))
@@ -443,20 +447,16 @@ CASES["six_layer_phil_300"] = (run_case, dict(forcing=PH, soil=SIX, pdm=2, subcy
 CASES["grad_six_layer_synth1"] = (run_case, dict(forcing="forcing_data_synth_1.txt", soil=SIX, pdm=0.0, subcycle_s=300, forcing_res_s=300, endtime_h=12.0, grad=True))
 
 
-def bench_member(col, n_columns=16384):
-    """Soil and forcing multiplier of column `col` of the benchmark ensemble (lgar_py_amd/workloads.py perturbed_columns
-    seed 0 / forcing_scale seed 1000, restated so this script does not import the package under test)."""
-    rng = np.random.default_rng(0)
+def bench_member(col, n_columns=16384, seed=0, scale_seed=1000, lo=0.5, hi=1.5):
+    """Soil and forcing multiplier of column `col` of a seeded +-10 % ensemble (lgar_py_amd/workloads.py perturbed_columns /
+    forcing_scale, restated so this script does not import the package under test); defaults: the benchmark ensemble."""
+    rng = np.random.default_rng(seed)
     out = dict(thickness=list(PHIL["thickness"]))
     for k in ["alpha", "n", "ksat", "theta_e", "theta_r"]:
         b = np.asarray(PHIL[k], dtype=np.float64)[:, None]
         out[k] = [float(v) for v in (b * (1.0 + 0.10 * (2.0 * rng.random((3, n_columns)) - 1.0)))[:, col]]
-    scale = float((0.5 + rng_scale(n_columns))[col])
+    scale = float((lo + (hi - lo) * np.random.default_rng(scale_seed).random(n_columns))[col])
     return out, scale
-
-
-def rng_scale(n_columns):
-    return np.random.default_rng(1000).random(n_columns)
 
 
 # Members of the benchmark ensemble in which the reference's own update drops one step's infiltration (top layer saturated,
@@ -466,6 +466,14 @@ for col in (15731, 10707):
     soil_, scale_ = bench_member(col)
     CASES["bench_col%d" % col] = (run_case, dict(forcing="forcing_data_synth_1.txt", soil=soil_, pdm=0.0, subcycle_s=300,
                                                   forcing_res_s=300, endtime_h=12.0, forcing_scale=scale_))
+
+
+# A member of a seeded hourly ensemble (tools/parity_sweep.py, shape "hourly", seed 0, column 1270) on which the reference
+# raises ValueError at step 277: a dry-over-wet deletion in layer 2 writes psi(theta of layer 2) with layer 1's parameters
+# into the fronts above (Layer.py:1117-1143), Se > 1, negative pow base -- a NaN that update_psi would overwrite unseen.
+soil_, scale_ = bench_member(1270, n_columns=4096, seed=400, scale_seed=500, lo=0.5, hi=3.0)
+CASES["crash_dry_over_wet_300"] = (run_case, dict(forcing=PH, soil=soil_, pdm=2, subcycle_s=3600, forcing_res_s=3600, endtime_h=300.0,
+                                                  forcing_scale=scale_, scale_pet=False))
 
 
 def _run(name):

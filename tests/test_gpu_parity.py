@@ -313,6 +313,35 @@ def test_heterogeneous_hourly_with_pet_vs_oracle_fp64():
         assert fr["n_fronts"][ok].max() <= 12
 
 
+def test_wet_hourly_ensemble_faults_where_the_oracle_does():
+    """4096 perturbed columns under the hourly forcing with rain multipliers up to 3 (tools/parity_sweep.py found this
+    shape): a few columns hit the reference's ValueError inside fix_dry_over_wet (psi of another layer's theta, Se > 1,
+    Layer.py:1117-1143; fixture crash_dry_over_wet_300 is the reference's own run of one of them) -- a NaN that update_psi
+    overwrites before anything reads it.  Every mode must flag exactly the oracle's columns and agree to 1e-6 elsewhere."""
+    import lgar_py_amd as lg
+    from lgar_py_amd import workloads as W
+    from oracle import lgar_oracle as O
+    g = np.load(os.path.join(GOLDEN, "phil_hourly_3000.npz"))
+    N, T = 4096, 600
+    P = W.perturbed_columns(N, seed=400)
+    sc = W.forcing_scale(N, 0.5, 3.0, seed=500)
+    pr = g["forcing"][:T, 0:1] * sc[None, :]
+    pe = g["forcing"][:T, 1:2] * np.ones((1, N))
+    ro, pc, acc, st = O.run_columns(P["alpha"], P["n"], P["ksat"], P["theta_e"], P["theta_r"], P["thickness"], pr, pe,
+                                    pdm=2.0, dt_h=1.0)
+    assert st[1270] != 0 and 0 < (st != 0).sum() < 100
+    for mode in (0, 1, 2):
+        eng = lg.LgarEngine(P["alpha"], P["n"], P["ksat"], P["theta_e"], P["theta_r"], P["thickness"], dt_h=1.0,
+                            ponded_depth_max=2.0, dtype=torch.float64, search_mode=mode)
+        out = eng.forward(torch.tensor(pr), torch.tensor(pe), series=("runoff",), check=False)
+        gst = eng.status.cpu().numpy()
+        assert ((st != 0) == (gst != 0)).all(), mode
+        ok = st == 0
+        assert np.abs(out["runoff"].cpu().numpy() - ro)[:, ok].max() <= 1e-6 * max(1.0, np.abs(ro).max()), mode
+        tot = eng.totals.cpu().numpy()
+        assert _rel(tot[:8, ok], acc[:8, ok], 1e-3).max() <= 1e-6, mode
+
+
 def test_wide_parameter_ensemble_vs_oracle_fp64():
     """BASELINE configs[4]'s parameter ranges (alpha in [0.0015, 0.015], n in [1.1, 3], Ksat in [0.01, 5]) under the
     synth_1 storm: kernel vs oracle per column; the same columns leave the reference's domain of validity."""
