@@ -3,7 +3,7 @@ test-suite cases, several seeds, both ensemble shapes and all three search modes
 and the worst relative error over the columns both sides integrate; exits 1 on a disagreement above 1e-6 (for the
 wide-parameter ensemble: on more than 0.1 % of the columns taking another branch, see the comment below).
 usage: python tools/parity_sweep.py [columns] [seeds]"""
-import json, os, sys, time
+import json, os, sys, time, zlib
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -65,5 +65,64 @@ for seed in range(SEEDS):
                 fail = True
                 bad = np.nonzero((st != 0) != (gst != 0))[0][:5]
                 print("  mismatching flags at columns", bad.tolist(), "oracle", st[bad].tolist(), "hip", gst[bad].tolist(), flush=True)
+
+# ---- second part: every configuration family of the golden fixtures (layer counts 2..6, closed-form G, frozen factor, initial
+# psi, sub-cycling, ponding limits), each soil perturbed +-10 % per column, rain scaled U(0.5, 2) per column
+FIXTURES = ["two_layer_synth1", "two_layer_phil_600", "four_layer_synth1", "four_layer_phil_600", "five_layer_synth1",
+            "five_layer_phil_500", "six_layer_synth1", "six_layer_phil_300", "closedG_synth1_phil", "closedG_generic_synth0_400",
+            "frozen07_synth1_phil", "frozen07_phil_hourly_400", "psi500_synth1_generic", "bushland_hourly_1500",
+            "generic_phil_forcing_1000", "phil_5min_600h", "synth3_generic", "manyfronts_pulse_84", "rand00", "rand02", "rand05",
+            "rand07", "rand09", "rand10"]
+NF = int(os.environ.get("SWEEP_FIXTURE_COLUMNS", 2048))
+for name in (FIXTURES if os.environ.get("SWEEP_FIXTURES", "1") != "0" else []):
+    g = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+    L = len(g["alpha"])
+    closed = bool(g["closed_form"]) if "closed_form" in g.files else False
+    n = NF // 4 if closed else NF
+    rng = np.random.default_rng(zlib.crc32(name.encode()))
+    P = {k: np.asarray(g[k], dtype=np.float64)[:, None] * (1.0 + 0.10 * (2.0 * rng.random((L, n)) - 1.0))
+         for k in ("alpha", "n", "ksat", "theta_e", "theta_r")}
+    P["thickness"] = np.repeat(np.asarray(g["thickness"], dtype=np.float64)[:, None], n, 1)
+    T = min(g["forcing"].shape[0], 400)
+    sc = 0.5 + 1.5 * rng.random(n)
+    pr = g["forcing"][:T, 0:1] * sc[None, :]
+    pe = np.repeat(g["forcing"][:T, 1:2], n, 1)
+    kw = dict(initial_psi=float(g["initial_psi"]), pdm=float(g["pdm"]), wp_psi=float(g["wilting_point_psi"]),
+              frozen_factor=float(g["frozen_factor"]), dt_h=float(g["dt_h"]), nint=int(g["nint"]),
+              num_subcycles=int(g["num_subcycles"]), giuh=tuple(g["giuh_ordinates"]))
+    if not closed:
+        ro, pc, acc, st = O.run_columns(P["alpha"], P["n"], P["ksat"], P["theta_e"], P["theta_r"], P["thickness"], pr, pe, **kw)
+    else:
+        ro = np.zeros((T, n)); acc = np.zeros((10, n)); st = np.zeros(n, dtype=np.int32)
+        for c in range(n):
+            pp = O.make_params(*(P[k][:, c] for k in ("alpha", "n", "ksat", "theta_e", "theta_r", "thickness")), **kw)
+            pp.closed_form = 1
+            ss = O.init_state(pp)
+            r = O.run(pp, ss, pr[:, c], pe[:, c], fronts=False)
+            ro[:, c] = r["acc"][:, 4]; acc[:, c] = r["acc"].sum(0); acc[9, c] = r["acc"][-1, 9]; st[c] = r["status"]
+    for mode in (1, 0, 2):
+        eng = lg.LgarEngine(P["alpha"], P["n"], P["ksat"], P["theta_e"], P["theta_r"], P["thickness"], dt_h=kw["dt_h"],
+                            num_subcycles=kw["num_subcycles"], ponded_depth_max=kw["pdm"], initial_psi=kw["initial_psi"],
+                            wilting_point_psi=kw["wp_psi"], frozen_factor=kw["frozen_factor"], nint=kw["nint"],
+                            giuh_ordinates=kw["giuh"], use_closed_form_G=closed, dtype=torch.float64, search_mode=mode)
+        out = eng.forward(torch.tensor(pr), torch.tensor(pe), series=("runoff",), check=False)
+        gst = eng.status.cpu().numpy() & 0x7f
+        both = (st == 0) & (gst == 0)
+        n_flag_diff = int(((st != 0) != (gst != 0)).sum())
+        got = out["runoff"].cpu().numpy()
+        col_err = np.abs(got - ro).max(0) / max(1.0, np.abs(ro).max())
+        tot = eng.totals.cpu().numpy()
+        e_tot = float((np.abs(tot[2:6] - acc[2:6]) / np.maximum(np.abs(acc[2:6]), 1e-3))[:, both].max()) if both.any() else 0.0
+        e_ro = float(col_err[both].max()) if both.any() else 0.0
+        rec = dict(fixture=name, layers=L, mode=mode, columns=n, steps=T, valid=float(both.mean()), flag_mismatches=n_flag_diff,
+                   columns_off_by_more_than_1e_6=int((col_err[both] > 1e-6).sum()), err_runoff=e_ro, err_totals=e_tot,
+                   max_fronts=int(eng.n_fronts.max()))
+        print(json.dumps(rec), flush=True)
+        worst = max(worst, e_ro, e_tot)
+        if n_flag_diff or max(e_ro, e_tot) > 1e-6:
+            fail = True
+            bad = np.nonzero(((st != 0) != (gst != 0)) | (both & (col_err > 1e-6)))[0][:6]
+            print("  differing columns", bad.tolist(), "oracle", st[bad].tolist(), "hip", gst[bad].tolist(),
+                  "err", [float(col_err[b]) for b in bad], flush=True)
 print(json.dumps(dict(worst=worst, failed=fail)))
 sys.exit(1 if fail else 0)
