@@ -61,7 +61,8 @@ extern "C" {
  * front-capacity chain at the step index held in bits 8..31 */
 #define LGAR_ST_RESUME 128
 #define LGAR_ST_STEP_SHIFT 8
-#define LGAR_NTICKETS 8   /* LgarState.tickets: one counter per kernel of a call's capacity chain (3 used) */
+#define LGAR_NTICKETS 8   /* LgarState.tickets: [0..2] one work counter per kernel of a call's capacity chain; [4..5] columns
+                             handed over by the first / second kernel (a next kernel with nothing to do exits at once) */
 #define LGAR_NCOUNTERS 4  /* LgarStepOut.counters: [0] wave-level Geff evaluations of the launch; [1..3] reserved */
 
 /* front flag byte: low 7 bits layer number, bit 7 = to_bottom (layers/WettingFront.py:39,49) */

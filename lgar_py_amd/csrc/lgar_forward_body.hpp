@@ -20,6 +20,8 @@ template <typename R> struct KArgs {
   int Nf, Fg;                                             // forcing columns and group: column c reads forcing column (c / Fg) % Nf
   unsigned *ticket;                                       // null, or the work counter of this launch (persistent waves)
   int chain_first, chain_last;                            // position in the capacity chain (see above)
+  const unsigned *pending_in;                             // null, or how many columns the previous kernel of the chain handed over
+  unsigned *pending_out;                                  // null, or where this kernel counts the columns it hands over
   const R *alpha, *n, *ksat, *theta_e, *theta_r, *thick;  // [NL][N]
   R *depth, *theta, *psi, *k, *dzdt;                      // [F][N]
   uint8_t *flags;                                         // [F][N]
@@ -65,10 +67,12 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 __device__ __forceinline__ void atomic_add(double *p, double v) { atomicAdd(p, v); }
 __device__ __forceinline__ void atomic_add(unsigned long long *p, unsigned long long v) { atomicAdd(p, v); }
+__device__ __forceinline__ void atomic_add(unsigned *p, unsigned v) { atomicAdd(p, v); }
 #else
 __device__ __forceinline__ double wave_sum(double v) { return v; }
 __device__ __forceinline__ void atomic_add(double *p, double v) { *p += v; }
 __device__ __forceinline__ void atomic_add(unsigned long long *p, unsigned long long v) { *p += v; }
+__device__ __forceinline__ void atomic_add(unsigned *p, unsigned v) { *p += v; }
 #endif
 
 // the kernel's argument block where it lies (kernarg segment); `launder` makes the compiler forget what it has already
@@ -277,6 +281,12 @@ __device__ __forceinline__ void forward_lane(const LGAR_KARG KArgs<R> *ap, size_
   }
   col.status &= LGAR_ST_FAULT_MASK;
   if (t_begin >= z.T) return;  // not this kernel's column (or a padding lane)
+  if (z.pending_out != nullptr) {
+    // columns handed to the next kernel of the chain are counted, so that a next kernel with nothing to do (the usual
+    // case) leaves after one load instead of scanning every status word
+    const unsigned long long m = any_lane(t_stop >= 0 && t_stop < z.T);
+    if (m != 0ull && first_active_lane()) atomic_add(z.pending_out, (unsigned)__builtin_popcountll(m));
+  }
   int word = col.status;
   if (t_stop >= 0 && t_stop < z.T) word |= LGAR_ST_RESUME | (int)((unsigned)t_stop << LGAR_ST_STEP_SHIFT);
   if (t_stop <= t_begin) {

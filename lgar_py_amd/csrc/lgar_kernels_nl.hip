@@ -50,6 +50,7 @@ __global__ __launch_bounds__(WAVE, (Occupancy<R, CAP>::waves)) void lgar_forward
   const LGAR_KARG KArgs<R> *ap = (const LGAR_KARG KArgs<R> *)__builtin_amdgcn_kernarg_segment_ptr();
   const size_t N = (size_t)ap->N;
   unsigned *ticket = ap->ticket;
+  if (ap->pending_in != nullptr && *ap->pending_in == 0u) return;  // no column was handed over to this kernel
   // With a ticket counter: persistent waves.  The grid is one wave per wave slot of the chip; each pulls 64-column blocks
   // from the counter until none is left, so no round of the grid is partially filled whatever the column count.
   // Without: one workgroup per block.
@@ -79,6 +80,8 @@ static KArgs<R> make_args(const LgarDims *d, const LgarParams *p, LgarState *s, 
   a.Nf = forcing_columns(d);
   a.Fg = forcing_group(d);
   a.ticket = nullptr;
+  a.pending_in = nullptr;
+  a.pending_out = nullptr;
   a.chain_first = a.chain_last = 1;
   a.alpha = (const R *)p->alpha; a.n = (const R *)p->n; a.ksat = (const R *)p->ksat;
   a.theta_e = (const R *)p->theta_e; a.theta_r = (const R *)p->theta_r; a.thick = (const R *)p->thickness;
@@ -157,6 +160,8 @@ static int forward_typed(const LgarDims *dims, const LgarParams *params, LgarSta
     a.chain_first = (i == 0);
     a.chain_last = (i == nc - 1);
     unsigned *tk = tickets ? tickets + i : nullptr;
+    a.pending_in = (tickets && i > 0) ? tickets + 4 + (i - 1) : nullptr;   // tickets[4..5]: columns handed over by kernel 0, 1
+    a.pending_out = (tickets && i < nc - 1) ? tickets + 4 + i : nullptr;
     switch (caps[i]) {
       case LGAR_CAP_SMALL: launch_forward_kernel<R, NL, LGAR_CAP_SMALL, 1>(a, grid, tk, st); break;
       case LGAR_CAP_MID: launch_forward_kernel<R, NL, LGAR_CAP_MID, 1>(a, grid, tk, st); break;

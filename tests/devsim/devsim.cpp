@@ -42,6 +42,8 @@ KArgs<R> make_args(const LgarDims *d, const LgarParams *p, LgarState *s, const L
   a.Nf = d->forcing_columns > 0 ? d->forcing_columns : d->n_columns / a.Fg;
   a.chain_first = a.chain_last = 1;
   a.ticket = nullptr;
+  a.pending_in = nullptr;
+  a.pending_out = nullptr;
   a.alpha = (const R *)p->alpha; a.n = (const R *)p->n; a.ksat = (const R *)p->ksat;
   a.theta_e = (const R *)p->theta_e; a.theta_r = (const R *)p->theta_r; a.thick = (const R *)p->thickness;
   a.depth = (R *)s->depth; a.theta = (R *)s->theta; a.psi = (R *)s->psi; a.k = (R *)s->k; a.dzdt = (R *)s->dzdt;
