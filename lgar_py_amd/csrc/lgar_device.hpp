@@ -401,7 +401,7 @@ template <> __device__ __forceinline__ float geff<float>(const LayerK<float> &l,
   // A column's result must not depend on which columns share its wavefront (safe_pairs is a property of the wave): node
   // pair p always sits at x0 + (2p+1, 2p+2) dx (one fma, never a running sum), always goes through the same operations,
   // and always lands in accumulator p & 1 -- whichever of the three loops below handles it.
-  f32x2 ja = {1.0f, 2.0f}, jb = {3.0f, 4.0f};
+  f32x2 ja = {1.0f, 2.0f};
   f32x2 acc = {0.0f, 0.0f}, accb = {0.0f, 0.0f};
   // one node pair: 4 transcendentals + 4 packed ops per node-pair -> sqrt(Se) and (1 - P Se)^2 of two nodes
 #define LGAR_GEFF_PAIR(X, SR, TT)                                              \
@@ -421,13 +421,12 @@ template <> __device__ __forceinline__ float geff<float>(const LayerK<float> &l,
   // four nodes per iteration: two independent chains
   for (; it + 1 < safe_pairs; it += 2) {
     const f32x2 xa = __builtin_elementwise_fma(ja, dx2, x02);
-    const f32x2 xb = __builtin_elementwise_fma(jb, dx2, x02);
+    const f32x2 xb = __builtin_elementwise_fma(ja + two2, dx2, x02);
     ja = ja + four2;
-    jb = jb + four2;
     f32x2 sa, ta, sb, tb;
     LGAR_GEFF_PAIR(xa, sa, ta)
-    LGAR_GEFF_PAIR(xb, sb, tb)
     acc = __builtin_elementwise_fma(sa, ta, acc);
+    LGAR_GEFF_PAIR(xb, sb, tb)
     accb = __builtin_elementwise_fma(sb, tb, accb);
   }
   if (it < safe_pairs) {  // `it` is even here
