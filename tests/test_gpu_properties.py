@@ -145,6 +145,39 @@ def test_head_of_the_full_job_matches_the_oracle(full_run):
     assert np.percentile(dro, 99) <= 5e-3 and dro.max() <= 5e-2
 
 
+def test_fp32_kernel_against_the_fp64_kernel_on_131072_columns():
+    """The throughput precision against the parity precision on the bench ensemble, at a size no CPU checker reaches: run
+    totals of the columns both integrate agree to 2e-5 (median) / 5e-3 (99th percentile) relative; the basin runoff of the
+    whole ensemble to 1e-3.  (fp32 cannot hold the reference's 1e-12 mass tolerance; a handful of columns take another
+    branch at a psi tie, hence percentiles -- DESIGN.md section 4.)"""
+    import lgar_py_amd as lg
+    from lgar_py_amd import workloads as W
+    N = 1 << 17
+    P = W.perturbed_columns(N, seed=0)
+    sc = W.forcing_scale(N, seed=1000)
+    f = W.synth1_forcing()
+    res = {}
+    for dt in (torch.float64, torch.float32):
+        eng = lg.LgarEngine(P["alpha"], P["n"], P["ksat"], P["theta_e"], P["theta_r"], P["thickness"], dt_h=300.0 / 3600.0,
+                            ponded_depth_max=0.0, dtype=dt)
+        pr = (torch.tensor(f[:, 0], device="cuda")[:, None] * torch.tensor(sc, device="cuda")[None, :]).to(dt).contiguous()
+        out = eng.forward(pr, torch.zeros_like(pr), series=(), basin=("runoff",), weights=None, check=False)
+        res[dt] = (eng.totals.double(), eng.status.clone(), out["basin:runoff"].clone())
+    t64, s64, b64 = res[torch.float64]
+    t32, s32, b32 = res[torch.float32]
+    ok = (s64 == 0) & (s32 == 0)
+    assert float(ok.double().mean()) > 0.8
+    for j, scale_row in ((3, 3), (4, 0), (9, 9)):  # infiltration, runoff (against the precipitation scale), end volume
+        r = ((t32[j] - t64[j]).abs() / torch.clamp(t64[scale_row].abs(), min=1.0))[ok].float()
+        assert float(r.median()) <= 2e-5, (j, float(r.median()))
+        assert float(torch.quantile(r, 0.99)) <= 5e-3, (j, float(torch.quantile(r, 0.99)))
+    # the basin sums include the few columns only one precision integrates to the end: compare on the common ones
+    w = ok.double()
+    tot32 = float((t32[4] * w).sum())
+    tot64 = float((t64[4] * w).sum())
+    assert abs(tot32 - tot64) <= 1e-3 * abs(tot64)
+
+
 def test_fp64_replicas_and_chunking_at_scale():
     """fp64 (the parity precision), 262 144 columns: replicas bitwise equal, and 3 launches of 48 steps = 1 launch of 144"""
     import lgar_py_amd as lg
