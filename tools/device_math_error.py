@@ -2,7 +2,6 @@
 long double (x87 extended: 64-bit mantissa).  Prints the worst errors; tests/test_gpu_parity.py asserts the bounds."""
 import json, os, sys
 import numpy as np
-import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import lgar_py_amd as lg
 
