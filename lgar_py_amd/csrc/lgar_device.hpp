@@ -567,17 +567,26 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
 
   __device__ __forceinline__ S cum_at(int k) const { return sel<S, NL>(P.cum, k); }
   // calc_geff (lgar/green_ampt.py:19-99): trapezoid or closed form, per cfg.data.use_closed_form_G
-  __device__ __forceinline__ S capillary_drive(const LayerK<S> &lk, S theta1, S theta2) {
+  __device__ __forceinline__ S capillary_drive(const LayerK<S> &lk, S theta1, S theta2, int site = 0) {
+    (void)site;
 #ifdef LGAR_ABL_NOGEFF  // register-pressure experiments (tools/): what the allocator does without the trapezoid
     return theta1 * theta2 + lk.alpha;
 #endif
     // one lane per wave-level evaluation adds 1 above the fault bits (no register, no LDS word; summed over the wave at the
     // end of the block): bits 8..31 of status are otherwise unused while a column is integrated
-#ifdef LGAR_COUNT_LANES  // measurement variant (tools/ablate.py): every evaluating lane counts
-    if (count_geff) status += (1 << LGAR_ST_STEP_SHIFT);
-#else
-    if (count_geff && first_active_lane()) status += (1 << LGAR_ST_STEP_SHIFT);
+#ifdef LGAR_COUNT_SITE  // measurement variants (tools/ablate.py): count one call site only (1 dzdt, 2 dry depth, 3 insert)
+    if (site == LGAR_COUNT_SITE)
 #endif
+#ifdef LGAR_COUNT_MAXLANES  // ... and only the evaluations with at most this many lanes taking part
+    if (__builtin_popcountll(any_lane(true)) <= LGAR_COUNT_MAXLANES)
+#endif
+    {
+#ifdef LGAR_COUNT_LANES  // measurement variant: every evaluating lane counts
+      if (count_geff) status += (1 << LGAR_ST_STEP_SHIFT);
+#else
+      if (count_geff && first_active_lane()) status += (1 << LGAR_ST_STEP_SHIFT);
+#endif
+    }
 #ifdef LGAR_DUP_GEFF
     if constexpr (sizeof(S) == sizeof(R)) {
       const S extra = geff(lk, opaque(theta1), opaque(theta2), G->nint);
@@ -1159,7 +1168,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
       S delta_theta = F.TH(i) - F.TH(i + 1);
       S dzdt = S(R(0.0));
       if (val(delta_theta) > R(0.0)) {
-        S g = capillary_drive(lk, theta_1, theta_2);
+        S g = capillary_drive(lk, theta_1, theta_2, 1);
         if (is_nan(val(g))) status |= LGAR_ST_NAN;
         const S ki = front_k(i, lk);
         if (k == 0) {
@@ -1187,7 +1196,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
     const LayerK<S> l0 = pick_static(P, 0);
     S delta_theta = l0.te - F.TH(0);
     S tau = G->dt_h * l0.ksat / delta_theta;
-    S g = capillary_drive(l0, F.TH(0), l0.te);
+    S g = capillary_drive(l0, F.TH(0), l0.te, 2);
     if (is_nan(val(g))) status |= LGAR_ST_NAN;
     S dry = R(0.5) * (tau + sq(tau * tau + R(4.0) * tau * g));
     return mn(P.cum[0], dry);
@@ -1239,7 +1248,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
     // quirk: with a fully saturated one-front top layer right after a layer crossing, nxt_i is a front of the
     // NEXT layer and Se > 1: the reference raises ValueError (negative pow base, physics/utils.py:25-27);
     // here the NaN is flagged and the IEEE min below drops it (all ponded water infiltrates).
-    if (nf != NL) g = capillary_drive(lk, F.TH(nxt_i < nf ? nxt_i : nf - 1), lk.te);
+    if (nf != NL) g = capillary_drive(lk, F.TH(nxt_i < nf ? nxt_i : nf - 1), lk.te, 3);
     if (is_nan(val(g))) status |= LGAR_ST_NAN | LGAR_ST_NEGBASE;
     S f_p;
     if (kfp == 0) {

@@ -29,6 +29,11 @@ VARIANTS = {
     "skeleton": ["-DLGAR_ABL_NOGEFF", "-DLGAR_ABL_NODZDT", "-DLGAR_ABL_NOMOVE", "-DLGAR_ABL_NOINSERT", "-DLGAR_ABL_NOEPILOGUE"],
     "contract": ["-ffp-contract=fast"],
     "count_lanes": ["-DLGAR_COUNT_LANES"],  # geff_calls then counts LANE-level evaluations (base: wave-level)
+    "site1_waves": ["-DLGAR_COUNT_SITE=1"], "site1_lanes": ["-DLGAR_COUNT_SITE=1", "-DLGAR_COUNT_LANES"],  # calc_dzdt
+    "site1_le16": ["-DLGAR_COUNT_SITE=1", "-DLGAR_COUNT_MAXLANES=16"], "site1_le32": ["-DLGAR_COUNT_SITE=1", "-DLGAR_COUNT_MAXLANES=32"],
+    "site1_le8": ["-DLGAR_COUNT_SITE=1", "-DLGAR_COUNT_MAXLANES=8"], "site1_le48": ["-DLGAR_COUNT_SITE=1", "-DLGAR_COUNT_MAXLANES=48"],
+    "site2_waves": ["-DLGAR_COUNT_SITE=2"], "site2_lanes": ["-DLGAR_COUNT_SITE=2", "-DLGAR_COUNT_LANES"],  # dry depth
+    "site3_waves": ["-DLGAR_COUNT_SITE=3"], "site3_lanes": ["-DLGAR_COUNT_SITE=3", "-DLGAR_COUNT_LANES"],  # insert_water
     "tan_nopair": ["-DLGAR_NO_FUSED_PAIR"],  # dual-number Geff one node per iteration (run tools/bench_autograd.py on it)
     "occ3": ["-DLGAR_OCC_F32_SMALL=3"],
     "occ2": ["-DLGAR_OCC_F32_SMALL=2"],
