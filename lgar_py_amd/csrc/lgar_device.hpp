@@ -1317,6 +1317,9 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
   // dpLGAR.forward, models/dpLGAR.py:154-299: one forcing step = nsub sub-steps
   __device__ __forceinline__ void forward(S precip, S pet) {
     const R dt = G->dt_h;
+    // a NaN in the forcing slips through the reference unnoticed (every comparison with it is false; the step's runoff comes
+    // out NaN, the front table stays finite): flagged here, a data fault the caller should hear about
+    if (is_nan(val(precip)) || is_nan(val(pet))) status |= LGAR_ST_NAN;
     S ending_volume_sub = ending_volume;
     for (int sub = 0; sub < G->nsub; sub++) {
       if (status & (LGAR_ST_BOTTOM | LGAR_ST_OVERFLOW | LGAR_ST_STRUCT)) return;  // dead column

@@ -262,3 +262,17 @@ def test_forcing_broadcast_equals_replicated_forcing():
     dirs2[1, 1::2] = 1.0
     g3, _, s3 = e.tangent({"ksat": dirs2}, pr3, pe3, w_runoff=w, forcing_group=2)
     assert np.array_equal(g3, g2[[0, 3, 1, 4, 2, 5]]) and (s3 == 0).all()
+
+
+def test_nan_in_the_forcing_is_flagged():
+    """The reference lets a NaN forcing value through (comparisons with it are false, the step's runoff is NaN, nothing
+    raises); the engine flags the column (LGAR_ST_NAN) so that the caller hears about the bad datum."""
+    g = np.load(os.path.join(GOLDEN, "synth1_phil.npz"))
+    f = g["forcing"].copy()
+    f[100, 0] = np.nan
+    for mode in (0, 1):
+        e = _engine(g, 2, search_mode=mode)
+        pr = np.stack([f[:, 0], g["forcing"][:, 0]], 1)
+        pe = np.stack([f[:, 1], g["forcing"][:, 1]], 1)
+        e.forward(pr, pe, series=("runoff",))
+        assert e.status[0] & 1 and e.status[1] == 0

@@ -282,6 +282,22 @@ def test_bad_arguments_are_rejected():
     assert out["runoff"].shape == (0, 4)
 
 
+def test_nan_in_the_forcing_is_flagged_on_gpu():
+    """A NaN forcing value slips through the reference silently; the engine flags that column and only that column."""
+    import lgar_py_amd as lg
+    g = np.load(os.path.join(GOLDEN, "synth1_phil.npz"))
+    for dtype in (torch.float64, torch.float32):
+        eng = _engine(g, 130, dtype)
+        pr, pe = _forcing(g, 130)
+        pr = pr.clone()
+        pr[100, 77] = float("nan")
+        eng.forward(pr, pe, series=(), check=False)
+        st = eng.status.cpu().numpy()
+        assert st[77] & 1 and (np.delete(st, 77) == 0).all()
+        with pytest.raises(lg.LgarStatusError):
+            eng.check_status()
+
+
 def test_heterogeneous_hourly_with_pet_vs_oracle_fp64():
     """Perturbed columns under the hourly Phillipsburg forcing (rain + PET: AET, dry-over-wet, merges, base case)
     scaled per column: kernel (literal searches) vs oracle column by column, 600 steps."""
