@@ -224,6 +224,12 @@ int32_t lgar_leaf_batch(int32_t op, int32_t n_items, const void *x, const void *
 #define LGAR_PROBE_READLANE 21 /* v_readlane_b32 (what an SGPR spill reload costs) */
 #define LGAR_PROBE_DS_READ 22  /* ds_read_b32, lane-contiguous */
 #define LGAR_PROBE_MIN 23      /* v_min_f32 */
+#define LGAR_PROBE_LDEXP64 24       /* v_ldexp_f64 */
+#define LGAR_PROBE_FREXP_EXP64 25   /* v_frexp_exp_i32_f64 */
+#define LGAR_PROBE_RNDNE64 26       /* v_rndne_f64 */
+#define LGAR_PROBE_CVT_I32_F64 27   /* v_cvt_i32_f64 */
+#define LGAR_PROBE_CVT_F64_I32 28   /* v_cvt_f64_i32 */
+#define LGAR_PROBE_ADD_U32 29       /* v_add_u32 */
 int32_t lgar_valu_probe_insts(int32_t op); /* wave-instructions per probe iteration: 64 (72 for LGAR_PROBE_GEFF_MIX) */
 int32_t lgar_valu_probe(int32_t op, int32_t n_workgroups, int32_t lds_bytes_per_workgroup, int32_t iters, void *sink,
                         void *stream);

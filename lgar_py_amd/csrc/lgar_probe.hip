@@ -117,6 +117,30 @@ template <int OP> __device__ __forceinline__ void probe_body(float (&v)[8], f32x
 #define X(i) asm volatile("v_min_f32 %0, %0, %1" : "+v"(v[i]) : "v"(c));
     REP64(X)
 #undef X
+  } else if (OP == LGAR_PROBE_LDEXP64) {
+#define X(i) asm volatile("v_ldexp_f64 %0, %0, %1" : "+v"(d[i]) : "v"(v[i]));
+    REP64(X)
+#undef X
+  } else if (OP == LGAR_PROBE_FREXP_EXP64) {
+#define X(i) asm volatile("v_frexp_exp_i32_f64 %0, %1" : "=v"(v[i]) : "v"(d[i]));
+    REP64(X)
+#undef X
+  } else if (OP == LGAR_PROBE_RNDNE64) {
+#define X(i) asm volatile("v_rndne_f64 %0, %0" : "+v"(d[i]));
+    REP64(X)
+#undef X
+  } else if (OP == LGAR_PROBE_CVT_I32_F64) {
+#define X(i) asm volatile("v_cvt_i32_f64 %0, %1" : "=v"(v[i]) : "v"(d[i]));
+    REP64(X)
+#undef X
+  } else if (OP == LGAR_PROBE_CVT_F64_I32) {
+#define X(i) asm volatile("v_cvt_f64_i32 %0, %1" : "=v"(d[i]) : "v"(v[i]));
+    REP64(X)
+#undef X
+  } else if (OP == LGAR_PROBE_ADD_U32) {
+#define X(i) asm volatile("v_add_u32 %0, %0, %1" : "+v"(v[i]) : "v"(c));
+    REP64(X)
+#undef X
   } else if (OP == LGAR_PROBE_GEFF_MIX) {
     // the instruction stream of one iteration of the lean fp32 Geff loop (lgar_device.hpp geff<float>: two trapezoid
     // nodes): 4 v_log + 4 v_exp + 3 v_pk_fma + 5 v_pk_mul + 2 v_pk_add, in program order with its dependences; four node
@@ -193,7 +217,8 @@ extern "C" int32_t lgar_valu_probe(int32_t op, int32_t n_workgroups, int32_t lds
     CASE(LGAR_PROBE_EXP_DEP) CASE(LGAR_PROBE_FMA_DEP) CASE(LGAR_PROBE_FMA64) CASE(LGAR_PROBE_MUL64)
     CASE(LGAR_PROBE_ADD64) CASE(LGAR_PROBE_RCP64) CASE(LGAR_PROBE_GEFF_MIX) CASE(LGAR_PROBE_CNDMASK_SGPR)
     CASE(LGAR_PROBE_BFI) CASE(LGAR_PROBE_CMP_CNDMASK) CASE(LGAR_PROBE_ADD) CASE(LGAR_PROBE_READLANE)
-    CASE(LGAR_PROBE_DS_READ) CASE(LGAR_PROBE_MIN)
+    CASE(LGAR_PROBE_DS_READ) CASE(LGAR_PROBE_MIN) CASE(LGAR_PROBE_LDEXP64) CASE(LGAR_PROBE_FREXP_EXP64)
+    CASE(LGAR_PROBE_RNDNE64) CASE(LGAR_PROBE_CVT_I32_F64) CASE(LGAR_PROBE_CVT_F64_I32) CASE(LGAR_PROBE_ADD_U32)
     default: return LGAR_E_ARG;
   }
 #undef CASE

@@ -12,7 +12,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lgar_py_amd import _capi
 
 OPS = ["exp", "log", "rcp", "sqrt", "fma", "mul", "pk_fma", "pk_mul", "cndmask", "cmp", "exp_dep", "fma_dep", "fma64",
-       "mul64", "add64", "rcp64", "geff_mix", "cndmask_sgpr", "bfi", "cmp_cndmask", "add", "readlane", "ds_read", "min"]
+       "mul64", "add64", "rcp64", "geff_mix", "cndmask_sgpr", "bfi", "cmp_cndmask", "add", "readlane", "ds_read", "min",
+       "ldexp64", "frexp_exp64", "rndne64", "cvt_i32_f64", "cvt_f64_i32", "add_u32"]
 
 
 def probe(op, waves_per_simd, iters=2000, rounds=4, n_cu=256):
