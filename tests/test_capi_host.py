@@ -91,3 +91,19 @@ def test_workloads_match_fixtures():
         b = [W.shard_bounds(n, w, r) for r in range(w)]
         assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
         assert max(h - l for l, h in b) - min(h - l for l, h in b) <= 1
+
+
+def test_integration_md_stub_matches_the_ctypes_mirror():
+    """INTEGRATION.md shows the binding a maintainer of the reference would add: its struct field lists must be the ones
+    lgar_py_amd/_capi.py (checked against include/lgar.h above) uses."""
+    import re
+    from lgar_py_amd import _capi
+    txt = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    i, j = txt.index("class LgarDims"), txt.index("class LgarParams")
+    assert re.findall(r'\("(\w+)"', txt[i:j]) == [f[0] for f in _capi.LgarDims._fields_]
+    for cls in ("LgarState", "LgarForcing", "LgarStepOut"):
+        line = txt[txt.index("class " + cls):]
+        line = line[:line.index("\n")]
+        m = re.search(r"for k in \(([^)]*)\)", line)
+        doc = [x.strip().strip('"') for x in m.group(1).split(",")] if m else re.findall(r'\("(\w+)"', line)
+        assert doc == [f[0] for f in getattr(_capi, cls)._fields_], cls
