@@ -447,6 +447,16 @@ CASES["six_layer_phil_300"] = (run_case, dict(forcing=PH, soil=SIX, pdm=2, subcy
 CASES["grad_six_layer_synth1"] = (run_case, dict(forcing="forcing_data_synth_1.txt", soil=SIX, pdm=0.0, subcycle_s=300, forcing_res_s=300, endtime_h=12.0, grad=True))
 
 
+# gradients through the option paths: closed-form G, frozen factor, another initial psi, two and five layers, and an hourly
+# run with PET and ponding (AET and ponded-water terms in the graph)
+CASES["grad_closedG_synth1"] = (run_case, dict(forcing="forcing_data_synth_1.txt", soil=PHIL, pdm=0.0, subcycle_s=300, forcing_res_s=300, endtime_h=12.0, closed_form=True, grad=True))
+CASES["grad_frozen07_synth1"] = (run_case, dict(forcing="forcing_data_synth_1.txt", soil=PHIL, pdm=0.0, subcycle_s=300, forcing_res_s=300, endtime_h=12.0, frozen_factor=0.7, grad=True))
+CASES["grad_psi500_generic"] = (run_case, dict(forcing="forcing_data_synth_1.txt", soil=GENERIC, pdm=0.0, subcycle_s=300, forcing_res_s=300, endtime_h=12.0, initial_psi=500.0, grad=True))
+CASES["grad_two_layer_phil_150"] = (run_case, dict(forcing=PH, soil=TWO, pdm=0.2, subcycle_s=3600, forcing_res_s=3600, endtime_h=150.0, grad=True,
+                                                   forcing_scale=6.0, scale_pet=False))
+CASES["grad_five_layer_synth1"] = (run_case, dict(forcing="forcing_data_synth_1.txt", soil=FIVE, pdm=0.0, subcycle_s=300, forcing_res_s=300, endtime_h=12.0, grad=True))
+
+
 def bench_member(col, n_columns=16384, seed=0, scale_seed=1000, lo=0.5, hi=1.5):
     """Soil and forcing multiplier of column `col` of a seeded +-10 % ensemble (lgar_py_amd/workloads.py perturbed_columns /
     forcing_scale, restated so this script does not import the package under test); defaults: the benchmark ensemble."""

@@ -20,7 +20,10 @@ def _setup(g, N, dtype=torch.float64, **kw):
     pe = f[:, 1:2].expand(T, N).contiguous()
     P = {k: torch.tensor(np.repeat(g[k][:, None], N, 1), device="cuda", dtype=dtype) for k in
          ("alpha", "n", "ksat", "theta_e", "theta_r", "thickness")}
-    ekw = dict(dt_h=float(g["dt_h"]), num_subcycles=int(g["num_subcycles"]), ponded_depth_max=float(g["pdm"]), dtype=dtype)
+    ekw = dict(dt_h=float(g["dt_h"]), num_subcycles=int(g["num_subcycles"]), ponded_depth_max=float(g["pdm"]), dtype=dtype,
+               initial_psi=float(g["initial_psi"]), wilting_point_psi=float(g["wilting_point_psi"]),
+               frozen_factor=float(g["frozen_factor"]), nint=int(g["nint"]), giuh_ordinates=tuple(g["giuh_ordinates"]),
+               use_closed_form_G=bool(g["closed_form"]) if "closed_form" in g.files else False)
     ekw.update(kw)
     return P, pr, pe, ekw
 
@@ -53,6 +56,8 @@ def test_gradients_match_reference_autograd(name, mode):
     for k, ref, direct in (("alpha", g["d_alpha"], ga), ("n", g["d_n"], gn), ("ksat", g["d_ksat"], gk)):
         got = P[k].grad[:, 0].cpu().numpy()
         ref = np.nan_to_num(ref, nan=0.0)  # None in the reference = no dependence
+        if k == "ksat":  # the reference's Parameter is Ksat x frozen_factor (models/dpLGAR.py:57), the engine's input is Ksat
+            ref = ref * float(g["frozen_factor"])
         scale = np.abs(ref).max()
         assert np.abs(got - ref).max() <= 1e-6 * scale, (k, got, ref)
         assert np.abs(P[k].grad[:, 1:].cpu().numpy()).max() == 0.0  # other columns do not enter the loss
@@ -154,6 +159,36 @@ def test_stepwise_model_backward_equals_series_backward(tmp_path):
         model(x[0])
     model.set_internal_states()
     model(x[0])
+
+
+def test_model_gradients_with_frozen_factor_follow_the_reference_convention(tmp_path):
+    """cfg.constants.frozen_factor = 0.7: the reference's Ksat Parameter IS Ksat x frozen_factor (models/dpLGAR.py:57), so
+    d loss / d model.ksat is taken with respect to the scaled value; the drop-in model reproduces the reference's own
+    gradients (fixture grad_frozen07_synth1), while the engine-level gradient is with respect to its unscaled input."""
+    from lgar_py_amd import config
+    from lgar_py_amd.model import MassBalance, dpLGAR
+    g = np.load(os.path.join(GOLDEN, "grad_frozen07_synth1.npz"))
+    os.makedirs(tmp_path / "data", exist_ok=True)
+    soil = write_soil_dat(str(tmp_path / "data" / "soil.dat"))
+    forcing = write_forcing(str(tmp_path / "data" / "f.csv"), g["forcing"], step_min=5)
+    cfg = config.load_config(cwd=str(tmp_path), overrides={
+        "data.forcing_file": forcing, "data.soil_params_file": soil, "data.ponded_depth_max": 0.0, "models.endtime": 12.0,
+        "models.subcycle_length": 300, "models.forcing_resolution": 300, "constants.frozen_factor": 0.7})
+    model = dpLGAR(cfg)
+    mb = MassBalance(cfg, model)
+    ys = []
+    x = torch.tensor(g["forcing"])
+    for i in range(x.shape[0]):
+        runoff, _ = model(x[i])
+        ys.append(runoff)
+        mb.change_mass(model)
+    loss = torch.mean(torch.stack(ys) ** 2)
+    assert abs(float(loss) - float(g["loss"])) <= 1e-9 * float(g["loss"])
+    loss.backward()
+    for plist, ref in ((model.alpha, g["d_alpha"]), (model.n, g["d_n"]), (model.ksat, g["d_ksat"])):
+        ref = np.nan_to_num(ref, nan=0.0)
+        got = np.array([float(p.grad) for p in plist])
+        assert np.abs(got - ref).max() <= 1e-6 * np.abs(ref).max(), (got, ref)
 
 
 def test_ensemble_gradients_config5_shape():
