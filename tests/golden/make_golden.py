@@ -478,6 +478,12 @@ for col in (15731, 10707):
                                                   forcing_res_s=300, endtime_h=12.0, forcing_scale=scale_))
 
 
+# Member 2 of the benchmark ensemble: the reference raises at step 127 -- top layer saturated right after a layer crossing,
+# insert_water takes Geff of the next layer's theta with layer-1 parameters (quirk q3), Se > 1, negative pow base.  This is
+# the fault 13 % of the benchmark's first draw hits in fp64 (bench.py re-draws those columns).
+soil_, scale_ = bench_member(2)
+CASES["crash_insert_water_bench_col2"] = (run_case, dict(forcing="forcing_data_synth_1.txt", soil=soil_, pdm=0.0, subcycle_s=300,
+                                                         forcing_res_s=300, endtime_h=12.0, forcing_scale=scale_))
 # A member of a seeded hourly ensemble (tools/parity_sweep.py, shape "hourly", seed 0, column 1270) on which the reference
 # raises ValueError at step 277: a dry-over-wet deletion in layer 2 writes psi(theta of layer 2) with layer 1's parameters
 # into the fronts above (Layer.py:1117-1143), Se > 1, negative pow base -- a NaN that update_psi would overwrite unseen.
