@@ -302,9 +302,9 @@ template <typename S> __device__ __forceinline__ S geff_fused(const LayerK<S> &l
   }
   int i = 0;
 #ifndef LGAR_NO_FUSED_PAIR
-  // dual numbers run at one wave per SIMD: two nodes per iteration give the scheduler two independent chains (same sums in
-  // the same order)
-  if constexpr (sizeof(S) != sizeof(R) && sizeof(R) == 8) {
+  // fp64 and its dual numbers: two nodes per iteration give the scheduler two independent chains (same sums in the same
+  // order; measured: backward -1.5 %, fp64 forward -1 %, a job of 157 waves -3 %)
+  if constexpr (sizeof(R) == 8) {
     for (; i + 1 < n_safe; i += 2) {
       const S hb = h2 + dh;
       const S ka = node(h2);
