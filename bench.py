@@ -158,8 +158,8 @@ def torch_eager_standin(target_s=3.0):
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--columns", type=int, default=1 << 20, help="columns per GPU")
     ap.add_argument("--tile", type=int, default=1, help="time tiling of the 144-row synth_1 forcing")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
