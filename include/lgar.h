@@ -101,6 +101,11 @@ typedef struct {
                                 forcing column (c / G) % forcing_columns; n_columns must be a multiple of G * forcing_columns.
                                 (The differentiable path puts the G parameter directions of one column in adjacent lanes:
                                 they take the same branches, so a wavefront diverges over 64 / G columns instead of 64.) */
+  int32_t tangent_share;     /* lgar_forward_tangent only.  0: every column stands alone.  8: the caller guarantees that each
+                                aligned group of 8 consecutive columns is ONE soil column (identical parameters and forcing)
+                                with 8 different directions; the 8 lanes then share the transcendentals of the Geff trapezoid
+                                (fp64 fast modes; ignored elsewhere).  n_columns must be a multiple of 8. */
+  int32_t reserved3;
 } LgarDims;
 
 /* Per-column soil parameters, each [n_layers][n_columns].  Replaces dpLGAR.alpha/.n/.ksat

@@ -31,7 +31,8 @@ class LgarDims(C.Structure):
                 ("search_mode", C.c_int32), ("bottom_mode", C.c_int32), ("use_closed_form_G", C.c_int32), ("front_slots", C.c_int32),
                 ("dt_h", C.c_double), ("initial_psi", C.c_double), ("ponded_depth_max", C.c_double),
                 ("wilting_point_psi", C.c_double), ("frozen_factor", C.c_double), ("giuh", C.c_double * GMAX),
-                ("iter_cap", C.c_int64), ("forcing_columns", C.c_int32), ("forcing_group", C.c_int32)]
+                ("iter_cap", C.c_int64), ("forcing_columns", C.c_int32), ("forcing_group", C.c_int32),
+                ("tangent_share", C.c_int32), ("reserved3", C.c_int32)]
 
 
 class LgarParams(C.Structure):

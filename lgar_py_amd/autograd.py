@@ -38,6 +38,11 @@ def parameter_vjp(eng, precip, pet, w_runoff, w_perc, wanted, check=True):
         return out, status
     group = max(1, min(D, BATCH_DIRECTIONS_MAX_COLUMNS // max(N, 1)))
     d = eng.dims
+    # fp64 fast modes: groups of exactly 8 directions let the 8 lanes of a column share the transcendentals of the Geff
+    # trapezoid (LgarDims.tangent_share); the remaining directions go as before
+    share8 = eng.dtype == torch.float64 and d.search_mode != 0 and not d.use_closed_form_G and group >= 8
+    if share8:
+        group = 8
     for g0 in range(0, D, group):
         part = wanted[g0:g0 + group]
         Dg = len(part)
@@ -61,7 +66,8 @@ def parameter_vjp(eng, precip, pet, w_runoff, w_perc, wanted, check=True):
         dirs = {k: torch.zeros(L, Dg * N, dtype=eng.dtype, device=eng.device) for k in KINDS}
         for b, (kind, l) in enumerate(part):
             dirs[kind][l, b::Dg] = 1.0
-        g, _, st = big.tangent(dirs, precip, pet, w_runoff=w_runoff, w_perc=w_perc, forcing_group=Dg)  # forcing / weights broadcast by the kernel
+        g, _, st = big.tangent(dirs, precip, pet, w_runoff=w_runoff, w_perc=w_perc, forcing_group=Dg,  # forcing / weights broadcast by the kernel
+                               share=8 if (share8 and Dg == 8) else 0)
         for b, key in enumerate(part):
             out[key] = g[b::Dg].contiguous()
             status |= st[b::Dg]

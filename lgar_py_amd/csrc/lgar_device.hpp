@@ -272,7 +272,23 @@ template <typename S> __device__ __forceinline__ S geff_node(const LayerK<S> &l,
   const S t = R(1.0) - P * (sqrt_se * sqrt_se);
   return l.ksat * sqrt_se * (t * t);
 }
-template <typename S> __device__ __forceinline__ S geff_fused(const LayerK<S> &l, S theta1, S theta2, int nint) {
+// Eight consecutive safe nodes of the trapezoid (h2, g, k1 advanced as eight passes of the plain loop would).  lgar_dual.hpp
+// overloads it for dual numbers whose eight neighbouring lanes carry the SAME column with different parameter directions:
+// each lane evaluates the transcendentals of one node and the eight exchange them.
+template <typename S>
+__device__ __forceinline__ void geff_block8(const LayerK<S> &l, const S &nm1, const S &half_m, S &h2, const S &dh, const S &hdh, S &g, S &k1,
+                                            real_t<S> *xchg) {
+  (void)xchg;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const S k2 = geff_node(l, nm1, half_m, h2);
+    g = g + ((k1 + k2) * hdh);
+    k1 = k2;
+    h2 = h2 + dh;
+  }
+}
+template <typename S>
+__device__ __forceinline__ S geff_fused(const LayerK<S> &l, S theta1, S theta2, int nint, real_t<S> *xchg = nullptr) {
   using R = real_t<S>;
   const S se_i = se_from_theta(l, theta1);
   const S se_f = se_from_theta(l, theta2);
@@ -301,6 +317,10 @@ template <typename S> __device__ __forceinline__ S geff_fused(const LayerK<S> &l
     }
   }
   int i = 0;
+  if constexpr (sizeof(S) != sizeof(R) && sizeof(R) == 8) {
+    if (xchg != nullptr)
+      for (; i + 7 < n_safe; i += 8) geff_block8(l, nm1, half_m, h2, dh, hdh, g, k1, xchg);
+  }
 #ifndef LGAR_NO_FUSED_PAIR
   // fp64 and its dual numbers: two nodes per iteration give the scheduler two independent chains (same sums in the same
   // order; measured: backward -1.5 %, fp64 forward -1 %, a job of 157 waves -3 %)
@@ -559,6 +579,8 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
   S k_deepest;
   bool new_front_frozen;
   bool count_geff = false;              // measurement: count wave-level Geff evaluations in the unused upper bits of `status`
+  int share_lanes = 0;                  // tangent kernels: 8 = my seven neighbours carry this same column (other directions)
+  R *xchg = nullptr;                    // ... and the wave's [4][64] LDS buffer they exchange trapezoid nodes through
   int cap = FMAX;                       // fronts this column may hold: min(kernel capacity, rows of the state arrays)
   // accumulators drained every forcing step (physics/MassBalance.py:45-53)
   S a_precip, a_pet, a_aet, a_infil, a_runoff, a_perc, a_giuh, a_disch;
@@ -597,6 +619,11 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
       // verification mode: the reference's trapezoid operation by operation (4 pow + sqrt per node, running h)
       return G->closed_form ? geff_closed<S, POL>(lk, theta1, theta2) : geff_literal<S, POL>(lk, theta1, theta2, G->nint);
     }
+#ifndef LGAR_NO_FUSED_GEFF
+    if constexpr (sizeof(S) != sizeof(R) && sizeof(R) == 8 && MODE != 0) {
+      if (share_lanes == 8 && !G->closed_form) return geff_fused<S>(lk, theta1, theta2, G->nint, xchg);
+    }
+#endif
     return G->closed_form ? geff_closed<S, POL>(lk, theta1, theta2) : geff(lk, theta1, theta2, G->nint);
   }
   __device__ __forceinline__ S cum_prev(int k) const {  // cum[k-1], 0 for k == 0

@@ -17,6 +17,7 @@ namespace lgar {
 
 template <typename R> struct TArgs {
   int N, T, Nf, Fg;  // Nf, Fg: columns of the forcing and weight arrays and group: column c reads column (c / Fg) % Nf
+  int share;         // 8: each aligned group of 8 columns is one soil column along 8 directions (LgarDims.tangent_share)
   int chain_first, chain_last;
   const R *alpha, *n, *ksat, *theta_e, *theta_r, *thick;  // [NL][N]
   const R *d_alpha, *d_n, *d_ksat;                        // [NL][N] or null
@@ -29,7 +30,8 @@ template <typename R> struct TArgs {
 };
 
 template <typename R, int NL, int FMAX, int MODE>
-__device__ __forceinline__ void tangent_lane(const LGAR_KARG TArgs<R> *ap, size_t c, int lane, WaveLDS<Dual<R>, FMAX, 1> &lds) {
+__device__ __forceinline__ void tangent_lane(const LGAR_KARG TArgs<R> *ap, size_t c, int lane, WaveLDS<Dual<R>, FMAX, 1> &lds,
+                                             R *xchg = nullptr) {
   using S = Dual<R>;
   const LGAR_KARG TArgs<R> &a = *ap;
   const size_t N = (size_t)a.N;
@@ -54,6 +56,8 @@ __device__ __forceinline__ void tangent_lane(const LGAR_KARG TArgs<R> *ap, size_
     P.cum[k] = (k == 0) ? P.thick[0] : P.cum[(k > 0) ? k - 1 : 0] + P.thick[k];
   }
   Column<S, NL, FMAX, MODE> col(P, &ap->G, make_view<S, FMAX>(&lds.f[0][0][0], &lds.fl[0][0], lane));
+  col.share_lanes = (xchg != nullptr) ? a.share : 0;
+  col.xchg = xchg;
   col.init_state();
   R grad = R(0);
   bool handed_over = false;

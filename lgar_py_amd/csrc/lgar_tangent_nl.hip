@@ -14,10 +14,11 @@ namespace lgar {
 
 template <typename R, int NL, int CAP, int MODE> __global__ __launch_bounds__(WAVE) void lgar_tangent_kernel(TArgs<R> a) {
   __shared__ WaveLDS<Dual<R>, CAP, 1> lds;
+  __shared__ R xchg[4][WAVE];  // tangent_share: the four transcendentals of a trapezoid node, one node per lane (lgar_dual.hpp)
   const int lane = threadIdx.x;
   const size_t c = (size_t)blockIdx.x * WAVE + lane;
   if (c >= (size_t)a.N) return;
-  tangent_lane<R, NL, CAP, MODE>((const LGAR_KARG TArgs<R> *)__builtin_amdgcn_kernarg_segment_ptr(), c, lane, lds);
+  tangent_lane<R, NL, CAP, MODE>((const LGAR_KARG TArgs<R> *)__builtin_amdgcn_kernarg_segment_ptr(), c, lane, lds, &xchg[0][0]);
 }
 
 template <typename R, int NL, int CAP, int MODE> static void launch_one(const TArgs<R> &a, unsigned grid, hipStream_t st) {
@@ -30,7 +31,7 @@ static int tangent_typed(const LgarDims *dims, const LgarParams *params, const L
                          const void *w_runoff, const void *w_perc, void *grad_out, void *tangent_runoff, int32_t *status,
                          hipStream_t st) {
   const unsigned grid = (unsigned)((dims->n_columns + WAVE - 1) / WAVE);
-  TArgs<R> a{dims->n_columns, dims->n_steps, forcing_columns(dims), forcing_group(dims), 1, 1, (const R *)params->alpha, (const R *)params->n, (const R *)params->ksat,
+  TArgs<R> a{dims->n_columns, dims->n_steps, forcing_columns(dims), forcing_group(dims), dims->tangent_share, 1, 1, (const R *)params->alpha, (const R *)params->n, (const R *)params->ksat,
              (const R *)params->theta_e, (const R *)params->theta_r, (const R *)params->thickness,
              (const R *)direction->alpha, (const R *)direction->n, (const R *)direction->ksat,
              (const R *)forcing->precip, (const R *)forcing->pet, (const R *)w_runoff, (const R *)w_perc,

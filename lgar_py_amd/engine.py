@@ -190,7 +190,7 @@ class LgarEngine:
             self.check_status()
         return res
 
-    def tangent(self, direction, precip, pet, w_runoff=None, w_perc=None, want_series=False, forcing_group=1):
+    def tangent(self, direction, precip, pet, w_runoff=None, w_perc=None, want_series=False, forcing_group=1, share=0):
         """Forward-mode tangent from a FRESH state (set_internal_states) over the whole forcing series.
 
         direction: {"alpha" | "n" | "ksat": [L, N] tensor} -- the parameter perturbation (missing = 0).
@@ -202,6 +202,9 @@ class LgarEngine:
         prep = lambda t: None if t is None else torch.as_tensor(t).to(self.device, self.dtype).contiguous()
         precip, pet, w_runoff, w_perc = prep(precip), prep(pet), prep(w_runoff), prep(w_perc)
         self._set_forcing_layout(precip, pet, forcing_group)
+        if share not in (0, 8) or (share == 8 and self.N % 8 != 0):
+            raise LgarError("share must be 0 or 8 (with n_columns a multiple of 8)")
+        self.dims.tangent_share = int(share)
         for nm, w in (("w_runoff", w_runoff), ("w_perc", w_perc)):
             if w is not None and w.shape != precip.shape:
                 raise LgarError("%s must be [T, N] like the forcing; got %s" % (nm, tuple(w.shape)))
