@@ -580,7 +580,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
   bool new_front_frozen;
   bool count_geff = false;              // measurement: count wave-level Geff evaluations in the unused upper bits of `status`
   int share_lanes = 0;                  // tangent kernels: 8 = my seven neighbours carry this same column (other directions)
-  R *xchg = nullptr;                    // ... and the wave's [4][64] LDS buffer they exchange trapezoid nodes through
+  R *xchg = nullptr;                    // ... and the wave's [5][64] LDS buffer they exchange trapezoid nodes through
   int cap = FMAX;                       // fronts this column may hold: min(kernel capacity, rows of the state arrays)
   // accumulators drained every forcing step (physics/MassBalance.py:45-53)
   S a_precip, a_pet, a_aet, a_infil, a_runoff, a_perc, a_giuh, a_disch;

@@ -133,84 +133,78 @@ __device__ __forceinline__ Dual<R> geff_node(const LayerK<Dual<R>> &l, const Dua
 #if !defined(LGAR_NO_FUSED_GEFF) && !defined(LGAR_GENERIC_DUAL_NODE) && !defined(LGAR_DEVSIM)
 // Eight nodes for eight lanes that integrate the SAME column along eight parameter directions (autograd.parameter_vjp lays
 // them side by side, LgarDims.tangent_share): the values -- and with them every branch -- are identical in the eight lanes,
-// only the tangents differ.  Lane r evaluates the four transcendentals of node r and leaves them in the wave's LDS buffer; every
-// lane then finishes all eight nodes with its own tangent (a few multiply-adds each).  Values and sums are those of eight passes
-// of the plain loop, bit for bit: same operations on the same operands, only computed once instead of eight times.
-template <int J>
-__device__ __forceinline__ void geff_block8_node(const LayerK<Dual<double>> &l, const Dual<double> &nm1, const Dual<double> &half_m,
-                                                 const Dual<double> &h, const double (&pr)[8][4], const Dual<double> &hdh,
-                                                 Dual<double> &g, Dual<double> &k1) {
+// only the tangents differ.  Lane r evaluates node r of an eight-node block and leaves the result in the wave's LDS buffer; every
+// lane then finishes all eight nodes with its own tangent.  The VALUES and their sums are those of eight passes of the plain loop,
+// bit for bit: same operations on the same operands, only computed once instead of eight times.
+// The tangent of a node is LINEAR in what differs between the eight lanes -- dx = d(alpha h), d(n-1), d(-m/2), dKsat:
+//   dK = A1 dx + A2 d(n-1) + A3 d(-m/2) + A4 dKsat,  with (B = 2 Ksat s t P s^2, W = K - 2 B, U = -m/2 (a/A) W)
+//   A1 = ((n U - (n-1) B) / x,  A2 = ln x (U - B),  A3 = ln A W,  A4 = s t^2
+// (geff_node's logarithmic-form tangent, collected by input).  So the lane that evaluates node r also evaluates K and A1..A4,
+// and the other seven finish that node with four multiply-adds.
+__device__ __forceinline__ void geff_block8(const LayerK<Dual<double>> &l, const Dual<double> &nm1, const Dual<double> &half_m,
+                                            Dual<double> &h2, const Dual<double> &dh, const Dual<double> &hdh, Dual<double> &g,
+                                            Dual<double> &k1, double *xchg) {
   const double LN2 = 0.6931471805599453;
-  const double lg = pr[J][0], Pv = pr[J][1], l1 = pr[J][2], sv = pr[J][3];
-  const double xv = l.alpha.v * h.v;
-  const double xd = l.alpha.d * h.v + l.alpha.v * h.d;
+  const int lane = (int)(threadIdx.x & 63u);
+  const int r = lane & 7;
+  // the eight heads, by the running sum of the plain loop
+  Dual<double> h[8];
+  h[0] = h2;
+#pragma unroll
+  for (int j = 1; j < 8; j++) h[j] = h[j - 1] + dh;
+  double hv = h[0].v;
+#pragma unroll
+  for (int j = 1; j < 8; j++) hv = (r == j) ? h[j].v : hv;
+  // my node: geff_node's value operations ...
+  const double xv = l.alpha.v * hv;
+  const double lg = lg2p(xv);
+  const double Pv = ex2p(nm1.v * lg);
   const double av = xv * Pv;
   const double Av = 1.0 + av;
+  const double l1 = lg2p(Av);
+  const double sv = ex2p(half_m.v * l1);
   const double Ps2 = Pv * (sv * sv);
   const double tv = 1.0 - Ps2;
   const double ks = l.ksat.v * sv;
   const double tt = tv * tv;
   const double Kv = ks * tt;
-  const double r = fast_recip(xv * Av);
-  const double dlnx = xd * (r * Av);
-  const double dlnP = (nm1.d * LN2) * lg + nm1.v * dlnx;
-  const double dlnA = (av * (r * xv)) * (dlnx + dlnP);
-  const double dlns = (half_m.d * LN2) * l1 + half_m.v * dlnA;
-  const double dt = -Ps2 * (dlnP + 2.0 * dlns);
-  const double Kd = l.ksat.d * (sv * tt) + Kv * dlns + (2.0 * (ks * tv)) * dt;
-  const Dual<double> k2(Kv, Kd);
-  g = g + ((k1 + k2) * hdh);
-  k1 = k2;
-}
-__device__ __forceinline__ void geff_block8(const LayerK<Dual<double>> &l, const Dual<double> &nm1, const Dual<double> &half_m,
-                                            Dual<double> &h2, const Dual<double> &dh, const Dual<double> &hdh, Dual<double> &g,
-                                            Dual<double> &k1, double *xchg) {
-  const int lane = (int)(threadIdx.x & 63u);
-  const int r = lane & 7;
-  // the eight heads, by the running sum of the plain loop
-  const Dual<double> h0 = h2, h1 = h0 + dh, h2_ = h1 + dh, h3 = h2_ + dh, h4 = h3 + dh, h5 = h4 + dh, h6 = h5 + dh, h7 = h6 + dh;
-  double hv = h0.v;
-  hv = (r == 1) ? h1.v : hv;
-  hv = (r == 2) ? h2_.v : hv;
-  hv = (r == 3) ? h3.v : hv;
-  hv = (r == 4) ? h4.v : hv;
-  hv = (r == 5) ? h5.v : hv;
-  hv = (r == 6) ? h6.v : hv;
-  hv = (r == 7) ? h7.v : hv;
-  // my node's transcendentals (geff_node's value operations)
-  const double xv = l.alpha.v * hv;
-  const double lg = lg2p(xv);
-  const double Pv = ex2p(nm1.v * lg);
-  const double l1 = lg2p(1.0 + xv * Pv);
-  const double sv = ex2p(half_m.v * l1);
+  // ... and the coefficients of its tangent
+  const double rc = fast_recip(xv * Av);  // one reciprocal serves 1/x and 1/A
+  const double B = (2.0 * (ks * tv)) * Ps2;
+  const double W = Kv - 2.0 * B;
+  const double U = (half_m.v * (av * (rc * xv))) * W;
+  const double A1 = (rc * Av) * ((1.0 + nm1.v) * U - nm1.v * B);
+  const double A2 = (LN2 * lg) * (U - B);
+  const double A3 = (LN2 * l1) * W;
+  const double A4 = sv * tt;
   // one wave = one workgroup: LDS operations of a wave complete in order, the fences only pin the compiler
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  xchg[0 * 64 + lane] = lg;
-  xchg[1 * 64 + lane] = Pv;
-  xchg[2 * 64 + lane] = l1;
-  xchg[3 * 64 + lane] = sv;
+  xchg[0 * 64 + lane] = Kv;
+  xchg[1 * 64 + lane] = A1;
+  xchg[2 * 64 + lane] = A2;
+  xchg[3 * 64 + lane] = A3;
+  xchg[4 * 64 + lane] = A4;
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   __builtin_amdgcn_wave_barrier();
-  // node J of this block was evaluated by lane J of my group of eight (same address in all eight lanes: an LDS broadcast);
-  // all 32 values are fetched before the first is used -- at one wave per SIMD nothing else hides an LDS round trip
+  // node j of this block was evaluated by lane j of my group of eight (same address in all eight lanes: an LDS broadcast)
   const double *grp = xchg + (lane & ~7);
-  double pr[8][4];
+  double pr[8][5];
 #pragma unroll
   for (int j = 0; j < 8; j++) {
 #pragma unroll
-    for (int v = 0; v < 4; v++) pr[j][v] = grp[v * 64 + j];
+    for (int v = 0; v < 5; v++) pr[j][v] = grp[v * 64 + j];
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // the next block's stores stay behind these loads
   __builtin_amdgcn_wave_barrier();
-  geff_block8_node<0>(l, nm1, half_m, h0, pr, hdh, g, k1);
-  geff_block8_node<1>(l, nm1, half_m, h1, pr, hdh, g, k1);
-  geff_block8_node<2>(l, nm1, half_m, h2_, pr, hdh, g, k1);
-  geff_block8_node<3>(l, nm1, half_m, h3, pr, hdh, g, k1);
-  geff_block8_node<4>(l, nm1, half_m, h4, pr, hdh, g, k1);
-  geff_block8_node<5>(l, nm1, half_m, h5, pr, hdh, g, k1);
-  geff_block8_node<6>(l, nm1, half_m, h6, pr, hdh, g, k1);
-  geff_block8_node<7>(l, nm1, half_m, h7, pr, hdh, g, k1);
-  h2 = h7 + dh;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const double xd = l.alpha.d * h[j].v + l.alpha.v * h[j].d;
+    const double Kd = pr[j][1] * xd + pr[j][2] * nm1.d + pr[j][3] * half_m.d + pr[j][4] * l.ksat.d;
+    const Dual<double> k2(pr[j][0], Kd);
+    g = g + ((k1 + k2) * hdh);
+    k1 = k2;
+  }
+  h2 = h[7] + dh;
 }
 #endif
 #ifndef LGAR_NO_FUSED_GEFF

@@ -14,7 +14,7 @@ namespace lgar {
 
 template <typename R, int NL, int CAP, int MODE> __global__ __launch_bounds__(WAVE) void lgar_tangent_kernel(TArgs<R> a) {
   __shared__ WaveLDS<Dual<R>, CAP, 1> lds;
-  __shared__ R xchg[4][WAVE];  // tangent_share: the four transcendentals of a trapezoid node, one node per lane (lgar_dual.hpp)
+  __shared__ R xchg[5][WAVE];  // tangent_share: K and the four tangent coefficients of a trapezoid node, one node per lane (lgar_dual.hpp)
   const int lane = threadIdx.x;
   const size_t c = (size_t)blockIdx.x * WAVE + lane;
   if (c >= (size_t)a.N) return;
