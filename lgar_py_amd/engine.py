@@ -204,6 +204,16 @@ class LgarEngine:
         self._set_forcing_layout(precip, pet, forcing_group)
         if share not in (0, 8) or (share == 8 and self.N % 8 != 0):
             raise LgarError("share must be 0 or 8 (with n_columns a multiple of 8)")
+        if share == 8:
+            # the kernel takes the caller's word that each aligned group of 8 columns is one soil column; a violation would
+            # give silently wrong gradients, so the wrapper checks (six small reductions)
+            for t in (self.alpha, self.n, self.ksat, self.theta_e, self.theta_r, self.thickness):
+                g8 = t.reshape(t.shape[0], -1, 8)
+                if not bool((g8 == g8[:, :, :1]).all()):
+                    raise LgarError("share=8 needs identical soil parameters within each aligned group of 8 columns")
+            if forcing_group % 8 != 0 and precip.shape[1] != 1:
+                raise LgarError("share=8 needs the 8 columns of a group to read the same forcing column (forcing_group a "
+                                "multiple of 8, or one forcing column for all)")
         self.dims.tangent_share = int(share)
         for nm, w in (("w_runoff", w_runoff), ("w_perc", w_perc)):
             if w is not None and w.shape != precip.shape:

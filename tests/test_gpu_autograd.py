@@ -312,3 +312,36 @@ def test_fp32_gradients_close_to_reference():
         ref = np.nan_to_num(ref, nan=0.0)
         got = P[k].grad[:, 0].double().cpu().numpy()
         assert np.abs(got - ref).max() <= 2e-2 * np.abs(ref).max(), (k, got, ref)
+
+
+def test_shared_tangent_launch_equals_plain_launch_and_rejects_mixed_groups():
+    """LgarDims.tangent_share = 8: eight direction-lanes of a column share the Geff trapezoid.  Gradients equal the plain
+    launch's to rounding (the values are bit-identical, the tangents are summed in another order), and the wrapper refuses
+    groups whose eight columns are not one soil column."""
+    import lgar_py_amd as lg
+    from lgar_py_amd import workloads as W
+    N = 512
+    E = W.ensemble_columns(N, seed=3)
+    f = W.synth1_forcing()
+    T = f.shape[0]
+    pr = torch.tensor(f[:, 0:1], device="cuda")
+    pe = torch.zeros_like(pr)
+    w = torch.rand(T, 1, device="cuda", dtype=torch.float64)
+    rep = {k: np.repeat(v, 8, axis=1) for k, v in E.items()}
+    eng = lg.LgarEngine(rep["alpha"], rep["n"], rep["ksat"], rep["theta_e"], rep["theta_r"], rep["thickness"],
+                        dt_h=300.0 / 3600.0, ponded_depth_max=0.0, dtype=torch.float64, with_state=False)
+    dirs = {k: torch.zeros(3, 8 * N, dtype=torch.float64, device="cuda") for k in ("alpha", "n", "ksat")}
+    for b, (kind, l) in enumerate([("alpha", 0), ("alpha", 1), ("n", 0), ("n", 1), ("n", 2), ("ksat", 0), ("ksat", 1), ("ksat", 2)]):
+        dirs[kind][l, b::8] = 1.0
+    g0, _, s0 = eng.tangent(dirs, pr, pe, w_runoff=w, forcing_group=8)
+    g1, _, s1 = eng.tangent(dirs, pr, pe, w_runoff=w, forcing_group=8, share=8)
+    assert torch.equal(s0, s1)
+    ok = (s0 & 0x7F) == 0
+    scale = float(g0[ok].abs().max())
+    assert float((g0 - g1)[ok].abs().max()) <= 1e-9 * scale and scale > 0
+    mixed = rep["ksat"].copy()
+    mixed[0, 3] *= 1.01
+    bad = lg.LgarEngine(rep["alpha"], rep["n"], mixed, rep["theta_e"], rep["theta_r"], rep["thickness"],
+                        dt_h=300.0 / 3600.0, ponded_depth_max=0.0, dtype=torch.float64, with_state=False)
+    with pytest.raises(lg.LgarError, match="identical soil parameters"):
+        bad.tangent(dirs, pr, pe, w_runoff=w, forcing_group=8, share=8)
