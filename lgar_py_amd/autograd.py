@@ -18,9 +18,10 @@ from ._capi import ST_FAULT_MASK
 from .engine import LgarEngine, LgarError, LgarStatusError
 
 KINDS = ("alpha", "n", "ksat")
-# all directions of a backward pass ride side by side as extra columns of ONE tangent launch (direction-major: column
-# b * N + c integrates column c's parameters perturbed in direction b); forcing and weights are NOT replicated -- the kernels
-# broadcast them (LgarDims.forcing_columns = N).  Above this many (column, direction) pairs the directions go in groups.
+# the directions of a backward pass ride side by side as extra columns of a tangent launch (column-major: column
+# c * D + b integrates column c's parameters perturbed in direction b, so that a column's directions sit in adjacent lanes);
+# forcing and weights are NOT replicated -- the kernels broadcast them (LgarDims.forcing_columns / forcing_group).  Above this
+# many (column, direction) pairs the directions go in groups; in fp64 fast modes groups of 8 share the Geff trapezoid.
 BATCH_DIRECTIONS_MAX_COLUMNS = 1 << 23
 
 
