@@ -97,7 +97,13 @@ __device__ __forceinline__ double fast_recip(double x) {
   return 1.0 / x;
 #endif
 }
-__device__ __forceinline__ float fast_recip(float x) { return 1.0f / x; }
+__device__ __forceinline__ float fast_recip(float x) {
+#ifndef LGAR_DEVSIM
+  return __builtin_amdgcn_rcpf(x);  // v_rcp_f32, 1 ulp: feeds derivatives only
+#else
+  return 1.0f / x;
+#endif
+}
 
 __device__ __forceinline__ double fast_pow(double x, double y) { return fast_exp2(y * fast_log2(x)); }
 
