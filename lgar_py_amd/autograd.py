@@ -23,6 +23,7 @@ KINDS = ("alpha", "n", "ksat")
 # forcing and weights are NOT replicated -- the kernels broadcast them (LgarDims.forcing_columns / forcing_group).  Above this
 # many (column, direction) pairs the directions go in groups; in fp64 fast modes groups of 8 share the Geff trapezoid.
 BATCH_DIRECTIONS_MAX_COLUMNS = 1 << 23
+SHARE_MIN_COLUMNS = 8192  # 8 lanes per column x 8192 columns = one wave on every SIMD of the chip
 
 
 def parameter_vjp(eng, precip, pet, w_runoff, w_perc, wanted, check=True):
@@ -41,7 +42,10 @@ def parameter_vjp(eng, precip, pet, w_runoff, w_perc, wanted, check=True):
     d = eng.dims
     # fp64 fast modes: groups of exactly 8 directions let the 8 lanes of a column share the transcendentals of the Geff
     # trapezoid (LgarDims.tangent_share); the remaining directions go as before
-    share8 = eng.dtype == torch.float64 and d.search_mode != 0 and not d.use_closed_form_G and group >= 8
+    # (only when the shared launch fills the chip: a small job is bound by the latency of ONE wave, and two launches in a row
+    # -- shared group, then the left-over directions -- would double it)
+    share8 = (eng.dtype == torch.float64 and d.search_mode != 0 and not d.use_closed_form_G and group >= 8
+              and N >= SHARE_MIN_COLUMNS)
     if share8:
         group = 8
     for g0 in range(0, D, group):

@@ -35,11 +35,16 @@ GRADS = [n for n in golden_names() if n.startswith("grad_")]
 
 @pytest.mark.parametrize("name", GRADS)
 @pytest.mark.parametrize("mode", [1, 2, 0], ids=["fast_search", "fast_capacity_chain", "literal_search"])
-def test_gradients_match_reference_autograd(name, mode):
+@pytest.mark.parametrize("shared", [False, True], ids=["one_launch", "shared_trapezoid"])
+def test_gradients_match_reference_autograd(name, mode, shared, monkeypatch):
     """Fixtures from the reference's own loss.backward(): nominal Phillipsburg, 4 layers, +-10 % ensemble members
     (grad_synth1_pert*), wide-range ensemble members (grad_wide*: BASELINE configs[4]'s parameter ranges) and a column
-    with up to 19 fronts (grad_manyfronts_60: more than the 8-slot tangent kernel holds -> capacity chain)."""
+    with up to 19 fronts (grad_manyfronts_60: more than the 8-slot tangent kernel holds -> capacity chain).  Both ways the
+    backward pass lays out its directions: all of a column's directions in one launch (small jobs), and eight of them
+    sharing the Geff trapezoid + the rest in a second launch (jobs that fill the chip; forced here)."""
+    import lgar_py_amd.autograd as A
     from lgar_py_amd.autograd import lgar_series
+    monkeypatch.setattr(A, "SHARE_MIN_COLUMNS", 1 if shared else 1 << 30)
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     N = 3
     P, pr, pe, ekw = _setup(g, N, search_mode=mode)
