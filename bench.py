@@ -14,6 +14,9 @@ Inputs are resident in HBM before the timed region.  Weak scaling: columns per G
 Without a launcher (`WORLD_SIZE` unset) and N > 1 the script starts its own N ranks, one fresh child process per GPU,
 BEFORE anything in this process touches the GPU.  Prints ONE JSON line on rank 0.
 LGAR_DIST_BACKEND=gloo is a rehearsal mode: the ranks may share GPUs and the [T] reduction goes through the host.
+LGAR_FORCE_DIST=1 makes `--gpus 1` take the multi-rank code path too: a fresh child process joins an RCCL ("nccl") group of
+world size 1 and every pass runs the real dist.all_reduce on the device [T] vector and the barriers of the timed region --
+what a one-GPU box can execute of configs[3]'s collective (the JSON line then says so under config.collective).
 """
 import argparse
 import json
@@ -190,13 +193,45 @@ def spawn_ranks(args):
                        "HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    rcs = [p.wait() for p in procs]
-    sys.stdout.write(out0 or "")
+    out0, failed = wait_ranks(procs)
+    sys.stdout.write(out0)
     sys.stdout.flush()
-    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
-    if bad:
-        raise SystemExit("bench.py: ranks failed: %s" % bad)
+    if failed is not None:
+        sys.stderr.write("bench.py: rank %d exited with code %d; the other ranks were stopped\n" % failed)
+        raise SystemExit(failed[1] if 0 < failed[1] < 256 else 1)
+
+
+def wait_ranks(procs, poll_s=0.05):
+    """Wait for the rank processes (rank 0's stdout is a pipe).  Returns (rank 0's output, None) when all exit with 0, else
+    (output so far, (rank, code)) of the first rank seen to fail -- after stopping its siblings, which would otherwise sit in
+    init_process_group / all_reduce until the RCCL timeout."""
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read() if procs[0].stdout else ""), daemon=True)
+    reader.start()
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            rc = p.poll()
+            if rc is not None and rc != 0:
+                failed = (r, rc)
+                break
+        time.sleep(poll_s)
+    if failed is not None:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    rcs = [p.wait() for p in procs]
+    reader.join(timeout=10)
+    if failed is None:
+        bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+        failed = bad[0] if bad else None
+    return "".join(c for c in chunks if c), failed
 
 
 def valu_probe_record(dev):
@@ -232,7 +267,8 @@ def valu_probe_record(dev):
 
 def main():
     args = parse_args()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    force_dist = os.environ.get("LGAR_FORCE_DIST", "0") == "1"
+    if (args.gpus > 1 or force_dist) and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args)
 
     import numpy as np
@@ -257,7 +293,8 @@ def main():
         raise SystemExit("--gpus %d but only %d visible (LGAR_DIST_BACKEND=gloo rehearses more ranks than GPUs)" % (world, ndev))
     dev = torch.device("cuda", local_rank % ndev)
     torch.cuda.set_device(dev)
-    if world > 1:
+    dist_on = world > 1 or force_dist  # LGAR_FORCE_DIST=1: the collective path with a group of one
+    if dist_on:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
@@ -343,7 +380,7 @@ def main():
         if i is not None:
             ev[i][1].record()
         basin = res["basin:runoff"]  # basin runoff per timestep [T] (fp64), reduced in the kernel epilogue
-        if world > 1:
+        if dist_on:
             all_reduce(basin)  # the only exchange of the path
         return basin
 
@@ -351,7 +388,7 @@ def main():
         step()
     torch.cuda.synchronize()
     eng.geff_wave_calls()  # reset the measurement counter
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -359,17 +396,17 @@ def main():
     for i in range(args.steps):
         basin = step(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if dist_on:
         all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else float("nan")
     faulted = torch.tensor([int((eng.status != 0).sum().item())], device=dev)
-    if world > 1:
+    if dist_on:
         all_reduce(faulted)
     geff_waves = eng.geff_wave_calls() / max(args.steps, 1)  # per launch
 
@@ -394,7 +431,8 @@ def main():
                        "columns_per_gpu": N, "timesteps_per_pass": T, "columns_redrawn_to_stay_in_reference_domain": resampled,
                        "domain_check": "every timed column runs to the end without a fault in fp32 and in fp64 (untimed set-up)",
                        "parallelism": "columns sharded x%d" % world,
-                       "collective": None if world == 1 else ("%s all-reduce of basin runoff [T]" % backend)},
+                       "collective": None if not dist_on else ("%s all-reduce of basin runoff [T], group of %d%s" % (
+                           backend, world, " (LGAR_FORCE_DIST=1)" if world == 1 else ""))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(N, T, args.dtype),
                          "traffic_note": "bytes per launch from separate rocprofv3 --pmc passes (profiles/*/traffic.json), not live",
@@ -505,7 +543,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

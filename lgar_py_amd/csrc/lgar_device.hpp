@@ -486,6 +486,117 @@ template <> __device__ __forceinline__ double geff<double>(const LayerK<double> 
   return geff_fused<double>(l, t1, t2, nint);
 }
 #endif
+
+// Mixed-precision Geff (LgarDims.geff_mode = 1, fp64 runs): the column state, every branch and the mass bookkeeping stay
+// in double precision; of the trapezoid, only the 119 INTERIOR nodes are evaluated with the fp32 hardware transcendentals.
+//   * both heads h(Se) (calc_h_from_se, utils.py:159-174), dh, and the two END nodes K(Se_i), K(Se_f)
+//     (calc_k_from_se, utils.py:134-156) are double precision.  K falls steeply with h (like h^-3.7 for the bundled soils),
+//     so over a wide range the wet end node carries most of the sum: it must not carry fp32 rounding;
+//   * interior node j sits at x_j = alpha h_i + j alpha dh, formed in double and rounded once to fp32; the exponents
+//     n - 1 and -m/2 enter as fp32 pairs hi + lo (their rounding would otherwise be a SYSTEMATIC relative error of
+//     ~1e-7 |log2 x| in every node; what remains -- the 1-ulp errors of v_log_f32 / v_exp_f32 and of x -- is random from
+//     node to node and averages over the sum);
+//   * the nodes' K_r are added up in double (per node pair: one fp32 add, one convert, one fp64 add).
+// Per interior node: the fp32 node's 4 transcendentals + ~6 packed/scalar fp32 operations + 2 fp64 operations, against the
+// ~93 fp64 instructions of the fused fp64 node.  The |h| < 0.1 -> Se = 1 rule and the wave-uniform select-free prefix are
+// those of the fp32 loop above; as there, a node pair always goes through the same operations into the same accumulator,
+// so a column's result does not depend on its wavefront.
+__device__ __forceinline__ double kr_from_se(const LayerK<double> &l, double se) {  // calc_k_from_se / Ksat
+  double base = 1.0 - pw(se, l.inv_m);
+  if (fabs(base) <= 1e-8) base = base + 1e-12;
+  const double t = 1.0 - pw(base, l.m);
+  return sqrt(se) * (t * t);
+}
+__device__ __forceinline__ double geff_mixed(const LayerK<double> &l, double theta1, double theta2, int nint) {
+  const double se_i = se_from_theta(l, theta1);
+  const double se_f = se_from_theta(l, theta2);
+  const double h_i = h_from_se(l, se_i);
+  const double h_f = h_from_se(l, se_f);
+  const double dh = (h_f - h_i) / double(nint);
+  const double x0 = l.alpha * h_i, dx = l.alpha * dh, xcut = 0.1 * l.alpha;
+  // exponents as fp32 pairs
+  const double nm1d = l.n - 1.0, hmd = -0.5 * l.m;
+  const float nm1 = (float)nm1d, nm1_lo = (float)(nm1d - (double)nm1);
+  const float hm = (float)hmd, hm_lo = (float)(hmd - (double)hm);
+  // K_r at Se == 1 (the 1e-12 nudge of calc_k_from_se): (1 - (1e-12)^m)^2
+  const double tsat = 1.0 - ex2p(l.m * -39.863137138648355);
+  const double ksat1 = tsat * tsat;
+  const float ksat1f = (float)ksat1;
+  const int M = nint - 1;  // interior nodes j = 1 .. nint-1
+  const int pairs = M >> 1;
+  const double jf = (x0 - xcut) / -dx - 1.5;
+  int safe = (jf > 0.0) ? ((jf < double(M)) ? int(jf) : M) : 0;  // NaN (dx == 0, or a head outside the domain) -> 0
+  safe >>= 1;
+  int safe_pairs = pairs;
+  if (any_lane(safe < pairs) != 0ull) {
+    safe_pairs = 0;
+    for (int bit = 64; bit; bit >>= 1) {
+      const int cand = safe_pairs + bit;
+      if (cand <= pairs && any_lane(safe < cand) == 0ull) safe_pairs = cand;
+    }
+  }
+  const float xcutf = (float)xcut;
+  const f32x2 nm12 = {nm1, nm1}, nm1l2 = {nm1_lo, nm1_lo}, hm2 = {hm, hm}, hml2 = {hm_lo, hm_lo}, one2 = {1.0f, 1.0f};
+  // one node pair: sqrt(Se) and (1 - P Se)^2 of the nodes at X.x, X.y
+#define LGAR_GEFFM_PAIR(X, SR, TT)                                                          \
+  {                                                                                         \
+    f32x2 lg, P, l1;                                                                        \
+    lg.x = lg2((X).x); lg.y = lg2((X).y);                                                   \
+    const f32x2 e0 = __builtin_elementwise_fma(nm12, lg, nm1l2 * lg);                       \
+    P.x = ex2(e0.x); P.y = ex2(e0.y);                                                       \
+    const f32x2 opa = __builtin_elementwise_fma((X), P, one2);                              \
+    l1.x = lg2(opa.x); l1.y = lg2(opa.y);                                                   \
+    const f32x2 e1 = __builtin_elementwise_fma(hm2, l1, hml2 * l1);                         \
+    (SR).x = ex2(e1.x); (SR).y = ex2(e1.y);                                                 \
+    const f32x2 t = __builtin_elementwise_fma(-P, (SR) * (SR), one2);                       \
+    (TT) = t * t;                                                                           \
+  }
+  double acc = 0.0, accb = 0.0;  // node pairs with even / odd index
+  int it = 0;
+  for (; it + 1 < safe_pairs; it += 2) {  // four nodes per iteration: two independent chains
+    const double j0 = double(2 * it + 1);
+    const f32x2 xa = {(float)fma(j0, dx, x0), (float)fma(j0 + 1.0, dx, x0)};
+    const f32x2 xb = {(float)fma(j0 + 2.0, dx, x0), (float)fma(j0 + 3.0, dx, x0)};
+    f32x2 sa, ta, sb, tb;
+    LGAR_GEFFM_PAIR(xa, sa, ta)
+    const f32x2 ka = sa * ta;
+    acc = acc + (double)(ka.x + ka.y);
+    LGAR_GEFFM_PAIR(xb, sb, tb)
+    const f32x2 kb = sb * tb;
+    accb = accb + (double)(kb.x + kb.y);
+  }
+  for (; it < pairs; it++) {  // the odd safe pair and the nodes that may fall under the |h| < 0.1 cut: K_r = ksat1 there
+    const double j0 = double(2 * it + 1);
+    const f32x2 x = {(float)fma(j0, dx, x0), (float)fma(j0 + 1.0, dx, x0)};
+    f32x2 sr, tt;
+    LGAR_GEFFM_PAIR(x, sr, tt)
+    if (it >= safe_pairs) {
+      sr.x = (x.x < xcutf) ? ksat1f : sr.x;
+      tt.x = (x.x < xcutf) ? 1.0f : tt.x;
+      sr.y = (x.y < xcutf) ? ksat1f : sr.y;
+      tt.y = (x.y < xcutf) ? 1.0f : tt.y;
+    }
+    const f32x2 k = sr * tt;
+    if (it & 1) accb = accb + (double)(k.x + k.y);
+    else acc = acc + (double)(k.x + k.y);
+  }
+  double sum = acc + accb;
+  if (M & 1) {  // odd number of interior nodes: the last one alone
+    const float x = (float)fma(double(M), dx, x0);
+    const f32x2 xx = {x, x};
+    f32x2 sr, tt;
+    LGAR_GEFFM_PAIR(xx, sr, tt)
+    sum = sum + (double)((x < xcutf) ? ksat1f : sr.x * tt.x);
+  }
+#undef LGAR_GEFFM_PAIR
+  // end nodes in double precision, with the reference's own formulas (|h| < 0.1 -> Se = 1 applies to the LAST node only:
+  // the first node's K is calc_k_from_se(Se_i) as it stands, green_ampt.py:60)
+  const double k0 = kr_from_se(l, se_i);
+  const double kn = (fabs(h_f) < 0.1 || h_f < 0.0) ? ksat1 : kr_from_se(l, se_from_h<double, 0>(l, h_f));
+  const double res = fabs((0.5 * dh) * ((k0 + kn) + 2.0 * sum));
+  const bool outside = is_nan(h_i) || is_nan(h_f);
+  return outside ? res + (h_i + h_f) : res;
+}
 #endif
 // calc_geff with use_closed_form_G (lgar/green_ampt.py:85-98): Brooks-Corey estimate from the van Genuchten parameters
 // (calc_bc_lambda / calc_bc_psib, physics/utils.py:54-64, 84-99).  Operator precedence as written in the reference:

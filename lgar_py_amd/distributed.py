@@ -5,10 +5,20 @@ are sharded identically, no halo, no data-path collective.  The ONE exchange of 
 reduction: an all-reduce(SUM) of the per-timestep runoff vector [T] after the time loop (RCCL over xGMI with the
 "nccl" backend; 576 B .. 24 KB, latency-bound).  The reference has no distributed code at all.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
 from .workloads import shard_bounds
+
+
+def _collective_on(group=None):
+    """A process group exists and the exchange has someone to talk to -- or LGAR_FORCE_DIST=1 asks for the collective to run
+    even in a group of one (how a one-GPU box executes the RCCL path of configs[3]: bench.py, tests/test_gpu_distributed.py)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or os.environ.get("LGAR_FORCE_DIST", "0") == "1"
 
 
 def world_info():
@@ -37,21 +47,21 @@ def basin_runoff(local_series, weights=None, group=None):
     if weights is not None:
         s = s * weights.to(torch.float64)[None, :]
     total = s.sum(dim=1)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if _collective_on(group):
         _all_reduce(total, group)
     return total
 
 
 def all_reduce_sum(t, group=None):
     """In-place all-reduce(SUM) of an already locally reduced tensor (e.g. the kernel's in-epilogue basin sums [T])."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if _collective_on(group):
         _all_reduce(t, group)
     return t
 
 
 def reduce_parameter_gradients(grads, group=None):
     """Shared-parameter training: all-reduce(SUM) of the [L x 3] gradient scalars."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if _collective_on(group):
         flat = torch.cat([g.reshape(-1) for g in grads])
         _all_reduce(flat, group)
         o = 0

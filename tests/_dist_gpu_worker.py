@@ -1,4 +1,4 @@
-"""Worker of tests/test_gpu_distributed.py: one rank of a gloo group; every rank drives the REAL HIP engine on the (shared)
+"""Worker of tests/test_gpu_distributed.py: one rank of a gloo group (or, LGAR_TEST_BACKEND=nccl, of an RCCL group); every rank drives the REAL HIP engine on the (shared)
 GPU through ShardedColumns and writes its shard's outputs to an .npz file."""
 import os
 import sys
@@ -23,7 +23,14 @@ def problem(N):
 def main():
     N, out = int(sys.argv[1]), sys.argv[2]
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
+    backend = os.environ.get("LGAR_TEST_BACKEND", "gloo")
+    grouped = world > 1 or backend == "nccl"
+    if backend == "nccl":
+        # RCCL group (of one on a one-GPU box; LGAR_FORCE_DIST=1 makes the exchange run all the same): before any other GPU call
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    elif world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     from lgar_py_amd.distributed import ShardedColumns
     P, pr, pe = problem(N)
@@ -31,7 +38,7 @@ def main():
     res, basin = sh.run(torch.tensor(sh.shard(pr)), torch.tensor(sh.shard(pe)), check=False)
     np.savez(out % rank, lo=sh.lo, hi=sh.hi, runoff=res["runoff"].cpu().numpy(), basin=basin.cpu().numpy(),
              status=sh.engine.status.cpu().numpy())
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -38,3 +38,22 @@ def test_cpu_baseline_leg_runs_on_a_tiny_sample(monkeypatch):
     monkeypatch.setenv("LGAR_CPU_THREADS", "2")
     r = b.cpu_baseline(target_s=0.3)
     assert r["kind"] == "port" and r["cores"] == 2 and r["value"] > 1e3 and "columns x 144 steps" in r["sample"]
+
+
+def test_wait_ranks_stops_the_siblings_of_a_failed_rank():
+    """a rank that dies early must not leave the others blocked until the RCCL timeout."""
+    import subprocess
+    import sys
+    import time
+    b = _bench()
+    t0 = time.time()
+    procs = [subprocess.Popen([sys.executable, "-c", "import time; print('rank0 up', flush=True); time.sleep(120)"],
+                              stdout=subprocess.PIPE, text=True),
+             subprocess.Popen([sys.executable, "-c", "import sys; sys.exit(3)"])]
+    out, failed = b.wait_ranks(procs)
+    assert failed == (1, 3) and time.time() - t0 < 30
+    assert all(p.poll() is not None for p in procs) and "rank0 up" in out
+    procs = [subprocess.Popen([sys.executable, "-c", "print('{\"ok\": 1}')"], stdout=subprocess.PIPE, text=True),
+             subprocess.Popen([sys.executable, "-c", "pass"])]
+    out, failed = b.wait_ranks(procs)
+    assert failed is None and out.strip() == '{"ok": 1}'

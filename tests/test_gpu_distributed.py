@@ -24,12 +24,13 @@ def _free_port():
     return p
 
 
-def _launch(world, N, out):
+def _launch(world, N, out, **extra_env):
     port = _free_port()
     procs = []
     for r in range(world):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        if world == 1:
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), **extra_env)
+        if world == 1 and not extra_env:
             env.pop("WORLD_SIZE")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_gpu_worker.py"), str(N), out], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
@@ -78,3 +79,59 @@ def test_bench_self_spawns_its_ranks():
     q = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
                         "--columns", "4096"], capture_output=True, text=True, env=env2, timeout=300)
     assert q.returncode != 0 and "WORLD_SIZE" in (q.stderr + q.stdout)
+
+
+@pytest.mark.timeout(900)
+def test_rccl_group_of_one_runs_the_real_all_reduce(tmp_path):
+    """configs[3]'s exchange on what one GPU can host: the worker joins an RCCL ("nccl") process group of world size 1 and,
+    with LGAR_FORCE_DIST=1, distributed.basin_runoff runs dist.all_reduce on the DEVICE [T] vector (no host hop).  The result
+    equals the run without a process group bit for bit (a sum over one rank)."""
+    N = 1000
+    _launch(1, N, str(tmp_path / "plain_%d.npz"))
+    _launch(1, N, str(tmp_path / "rccl_%d.npz"), LGAR_TEST_BACKEND="nccl", LGAR_FORCE_DIST="1")
+    a, b = np.load(tmp_path / "plain_0.npz"), np.load(tmp_path / "rccl_0.npz")
+    assert np.array_equal(a["runoff"], b["runoff"], equal_nan=True) and np.array_equal(a["status"], b["status"])
+    assert np.array_equal(a["basin"], b["basin"]) and b["basin"].sum() > 0
+
+
+@pytest.mark.timeout(900)
+def test_bench_takes_the_rccl_path_with_one_gpu():
+    """`LGAR_FORCE_DIST=1 python bench.py --gpus 1`: a fresh child initialises backend "nccl" (RCCL) with world size 1
+    before any GPU call, and every pass all-reduces the device [T] vector and crosses the barriers of the timed region --
+    bench.py's N > 1 code path, executed."""
+    env = dict(os.environ, LGAR_FORCE_DIST="1", LGAR_CPU_THREADS="2")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LGAR_DIST_BACKEND"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                        "--columns", "65536", "--no-extras", "--no-cpu-baseline"], capture_output=True, text=True, env=env,
+                       timeout=800)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and "nccl all-reduce" in d["config"]["collective"] and "group of 1" in d["config"]["collective"]
+    assert d["faulted_columns"] == 0 and d["basin_runoff_total_cm"] > 0
+    # the same job without the group: same basin total (the all-reduce over one rank is the identity)
+    env.pop("LGAR_FORCE_DIST")
+    q = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                        "--columns", "65536", "--no-extras", "--no-cpu-baseline"], capture_output=True, text=True, env=env,
+                       timeout=800)
+    assert q.returncode == 0, q.stderr[-3000:]
+    e = json.loads([ln for ln in q.stdout.splitlines() if ln.strip().startswith("{")][0])
+    assert e["config"]["collective"] is None
+    assert abs(e["basin_runoff_total_cm"] - d["basin_runoff_total_cm"]) <= 1e-9 * abs(e["basin_runoff_total_cm"])
+
+
+def test_a_failing_rank_stops_its_siblings_instead_of_hanging():
+    """bench.py --gpus 2 whose rank 1 cannot start (backend nccl, one visible GPU): the spawner reports the failure and stops
+    rank 0 instead of leaving it in the rendezvous until the RCCL timeout."""
+    import time
+    env = dict(os.environ, LGAR_DIST_BACKEND="nccl")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LGAR_FORCE_DIST"):
+        env.pop(k, None)
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--columns", "4096", "--no-extras", "--no-cpu-baseline"], capture_output=True, text=True, env=env,
+                       timeout=300)
+    assert p.returncode != 0 and "only 1 visible" in (p.stderr + p.stdout)
+    assert time.time() - t0 < 200
