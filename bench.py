@@ -313,7 +313,7 @@ def main():
     elem = 4 if args.dtype == "f32" else 8
     N = args.columns
 
-    def make_workload(kind, n_cols, dt, seed_rank):
+    def make_workload(kind, n_cols, dt, seed_rank, **eng_kw):
         """(engine, precip[T, N], pet[T, N], redrawn) with inputs resident in HBM."""
         if kind == "phillipsburg":
             g = np.load(os.path.join(ROOT, "tests", "golden", "phil_hourly_3000.npz"))  # first 3000 rows of the bundled forcing
@@ -328,7 +328,7 @@ def main():
             P = W.perturbed_columns(n_cols, seed=seed_rank)  # rank r holds columns [r*N, (r+1)*N) of the job; seed = shard index
             sc = torch.tensor(W.forcing_scale(n_cols, seed=1000 + seed_rank), device=dev)
             eng = lg.LgarEngine(P["alpha"], P["n"], P["ksat"], P["theta_e"], P["theta_r"], P["thickness"],
-                                dt_h=300.0 / 3600.0, ponded_depth_max=0.0, dtype=dt, device=dev)
+                                dt_h=300.0 / 3600.0, ponded_depth_max=0.0, dtype=dt, device=dev, **eng_kw)
         pr = (torch.tensor(f[:, 0], device=dev)[:, None] * sc[None, :]).to(dt).contiguous()
         pe = (torch.tensor(f[:, 1], device=dev)[:, None] * torch.ones_like(sc)[None, :]).to(dt).contiguous()
         # Keep the ensemble inside the reference's domain of validity (untimed set-up): a perturbed column whose
@@ -488,6 +488,26 @@ def main():
                                 "timesteps": T, "dtype": "f64", "workload": "same synth_1 ensemble, fp64 (parity precision)",
                                 "roofline_frac_hbm": alg_bytes_per_col_step(8, T) * N * T / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
                 del e64, p64, q64
+                # fp64 column state with the fp32 hardware transcendentals inside the Geff trapezoid (LgarDims.geff_mode = 1):
+                # run totals of every column within 2e-6 of the native fp64 kernels', identical fault flags (tests/test_gpu_mixed.py)
+                emx, pmx, qmx, _ = make_workload("synth1", N, torch.float64, rank, geff_precision="f32")
+                ms = []
+                for _ in range(3):
+                    emx.reset()
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record()
+                    emx.forward(pmx, qmx, series=("runoff", "percolation"), basin=("runoff",), check=False)
+                    b.record()
+                    torch.cuda.synchronize()
+                    ms.append(a.elapsed_time(b))
+                ms = min(ms[1:])
+                subs["fp64_state_f32_geff"] = {
+                    "value": N * T / (ms * 1e-3), "unit": "column-timesteps/s", "kernel_ms": ms, "columns": N, "timesteps": T,
+                    "dtype": "f64 state / f32 trapezoid nodes",
+                    "workload": "same synth_1 ensemble, mixed precision (geff_precision='f32')",
+                    "faulted_columns": int((emx.status != 0).sum().item()),
+                    "roofline_frac_hbm": alg_bytes_per_col_step(8, T) * N * T / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                del emx, pmx, qmx
             ec, pc, qc, _ = make_workload("phillipsburg", 10_000, torch.float64, 0)
             Tc = pc.shape[0]
             ms = []

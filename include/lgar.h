@@ -105,7 +105,15 @@ typedef struct {
                                 aligned group of 8 consecutive columns is ONE soil column (identical parameters and forcing)
                                 with 8 different directions; the 8 lanes then share the transcendentals of the Geff trapezoid
                                 (fp64 fast modes; ignored elsewhere).  n_columns must be a multiple of 8. */
-  int32_t reserved3;
+  int32_t geff_mode;         /* 0: the Geff trapezoid (lgar/green_ampt.py:45-84) in the precision of `dtype`.  1 (LGAR_F64 fast
+                                modes only; ignored elsewhere): mixed precision -- column state, branches and mass bookkeeping
+                                stay fp64, the two heads and the two end nodes of the trapezoid stay fp64, its 119 interior
+                                nodes use the fp32 hardware transcendentals and are summed in fp64 */
+  int32_t forward_lanes;     /* lgar_forward, LGAR_F64 fast modes with the trapezoid (ignored elsewhere).  0: the library decides --
+                                jobs too small to fill the chip get 2..64 cooperating lanes per column, which split the nodes of
+                                the Geff trapezoid between them (results bit for bit those of one lane per column); 1: one lane
+                                per column whatever the job size; 2, 4, .. 64: that many */
+  int32_t reserved4;
 } LgarDims;
 
 /* Per-column soil parameters, each [n_layers][n_columns].  Replaces dpLGAR.alpha/.n/.ksat
@@ -195,6 +203,7 @@ int32_t lgar_forward_tangent(const LgarDims *dims, const LgarParams *params, con
  * op 5 aet(psi = x, pet = y, dt_h = z)                                      (lgar/aet.py:17-51)
  * op 7 log2(x), 8 exp2(x) as the Geff trapezoid evaluates them, 9 pow(x, y) as the fast modes evaluate torch.pow
  *      (accuracy of the device arithmetic on the real hardware; soil parameters unused but required)
+ * op 10 geff(theta1 = x, theta2 = y) by the mixed-precision trapezoid of LgarDims.geff_mode = 1 (LGAR_F64; LGAR_F32: op 4)
  * alpha, n, ksat, theta_e, theta_r: [n] per-item soil parameters. */
 int32_t lgar_leaf_batch(int32_t op, int32_t n_items, const void *x, const void *y, double z, const void *alpha,
                         const void *n, const void *ksat, const void *theta_e, const void *theta_r, int32_t nint,

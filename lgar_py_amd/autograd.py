@@ -97,6 +97,15 @@ class LgarSeriesFunction(torch.autograd.Function):
         check = engine_kw.pop("check", True)
         status_out = engine_kw.pop("status_out", None)
         eng = LgarEngine(alpha.detach(), n.detach(), ksat.detach(), theta_e, theta_r, thickness, **engine_kw)
+        precip, pet = torch.as_tensor(precip), torch.as_tensor(pet)
+        if precip.dim() == 2 and precip.shape[1] != eng.N:
+            # broadcast forcing [T, Nf]: the backward pass pairs the forcing with the incoming [T, N] gradient column by
+            # column (the tangent kernels take one layout for both), so the series is expanded here, once
+            if eng.N % max(int(precip.shape[1]), 1) != 0 or precip.shape != pet.shape:
+                raise LgarError("forcing must be [T, N] or [T, Nf] with Nf dividing N = %d; got %s / %s"
+                                % (eng.N, tuple(precip.shape), tuple(pet.shape)))
+            rep = eng.N // int(precip.shape[1])
+            precip, pet = precip.repeat(1, rep).contiguous(), pet.repeat(1, rep).contiguous()  # column c reads c % Nf
         out = eng.forward(precip, pet, series=("runoff", "percolation"), check=check)
         if status_out is not None:
             status_out.append(eng.status)
@@ -188,9 +197,18 @@ class StepTape:
             raise LgarError("the model this tape belongs to is gone")
         return m, (("alpha", m.alpha), ("n", m.n), ("ksat", m.ksat))
 
-    def record(self, x_chunk, runoff_chunk, perc_chunk):
-        """x_chunk [Tc, N, 2]; runoff/perc [Tc, N] (engine outputs).  Returns the graph-connected blocks."""
+    def record(self, x_chunk, runoff_chunk, perc_chunk, steps_before=None):
+        """x_chunk [Tc, N, 2]; runoff/perc [Tc, N] (engine outputs); steps_before: forcing rows the model had integrated
+        since set_internal_states() before this chunk.  Returns the graph-connected blocks."""
         m, plists = self._param_lists()
+        recorded = sum(int(xc.shape[0]) for xc in self.x)
+        if steps_before is not None and steps_before != recorded:
+            # finalize() re-integrates the tangent from a FRESH state over the recorded rows only: rows the model advanced
+            # off the tape (under torch.no_grad(), or while no parameter required grad -- a spin-up, say) would make the
+            # backward pass replay another forcing series and another state than the forward run
+            raise LgarError("the model advanced %d forcing rows since set_internal_states() that are not on the autograd tape "
+                            "(%d recorded): forward() calls under torch.no_grad() cannot be mixed with differentiated ones "
+                            "within one series; call set_internal_states() first" % (steps_before - recorded, recorded))
         params = [p for _, pl in plists for p in pl]
         versions = tuple(p._version for p in params)
         if self.versions is None:
@@ -217,6 +235,9 @@ class StepTape:
         eng = m.engine
         X = torch.cat(self.x).to(eng.device, eng.dtype)  # [T, N, 2]
         T = X.shape[0]
+        if getattr(m, "steps_advanced", T) != T:
+            raise LgarError("the tape holds %d forcing rows but the model advanced %d since set_internal_states(): the gradient "
+                            "would belong to another run" % (T, m.steps_advanced))
         W = torch.zeros(2, T, eng.N, dtype=eng.dtype, device=eng.device)
         t0 = 0
         for ci, xc in enumerate(self.x):

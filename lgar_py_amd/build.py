@@ -1,4 +1,6 @@
 """Build the HIP library (liblgar_hip.so) in-tree for gfx950 with hipcc."""
+import contextlib
+import fcntl
 import hashlib
 import os
 import shutil
@@ -14,7 +16,7 @@ UNITS = [("lgar_kernels.hip", [], ""), ("lgar_probe.hip", [], "")] + \
         [("lgar_tangent_nl.hip", ["-DLGAR_NL=%d" % n], "_%d" % n) for n in LAYERS]
 SOURCES = sorted(set(u[0] for u in UNITS))
 HEADERS = ["lgar_device.hpp", "lgar_dual.hpp", "lgar_math.hpp", "lgar_host.hpp", "lgar_launch.hpp", "lgar_forward_body.hpp",
-           "lgar_tangent_body.hpp", os.path.join("..", "..", "include", "lgar.h")]
+           "lgar_tangent_body.hpp", "lgar_measure.hpp", os.path.join("..", "..", "include", "lgar.h")]
 # -ffp-contract=off: expression rounding follows the reference's Python (no FMA contraction)
 # fp32 division stays correctly rounded: with the rcp-based fast divide x/x != 1, Se = (theta-theta_r)/(theta_e-theta_r)
 # exceeds 1 at saturation and 8 % of perturbed columns fault (measured), for no speed gain.
@@ -48,33 +50,66 @@ def _stamp(lib, extra=()):
         fh.write(_fingerprint(extra) + "\n")
 
 
-def _compile_all(units, objdir, tag, extra, verbose):
-    """Compile translation units concurrently (JOBS at a time); an object is reused if it is newer than every source."""
+@contextlib.contextmanager
+def _locked(path):
+    """One builder at a time per output: every rank of `bench.py --gpus N` / torchrun reaches _capi.load() -> build() together
+    on a fresh checkout (the .so and its stamp are not in the repository)."""
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path + ".lock", "w") as fh:
+        fcntl.flock(fh, fcntl.LOCK_EX)
+        try:
+            yield
+        finally:
+            fcntl.flock(fh, fcntl.LOCK_UN)
+
+
+def _compile_all(units, objroot, tag, extra, verbose):
+    """Compile translation units concurrently (JOBS at a time).  Objects live in a directory named after the content
+    fingerprint (sources, headers AND flags), so an object is only ever reused by the exact build it was made for: a change of
+    FLAGS, of a unit's flags or of a header can never relink stale objects.  Older fingerprints' directories are removed."""
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build liblgar_hip.so")
+    fp = hashlib.sha256((_fingerprint(extra) + "|" + repr([(u[0], u[1], u[2]) for u in UNITS])).encode()).hexdigest()[:16]
+    objdir = os.path.join(objroot, fp)
+    if os.path.isdir(objroot):
+        for d in os.listdir(objroot):
+            full = os.path.join(objroot, d)
+            if d != fp and (os.path.isdir(full) and len(d) == 16 or d.endswith(".o")):
+                shutil.rmtree(full, ignore_errors=True) if os.path.isdir(full) else os.remove(full)
     os.makedirs(objdir, exist_ok=True)
     cflags = [f for f in FLAGS if f != "-shared"] + list(extra)
-    newest = max(os.path.getmtime(os.path.join(CSRC, f)) for f in SOURCES + HEADERS if os.path.exists(os.path.join(CSRC, f)))
     objs, todo = [], []
     for src, uflags, suffix in units:
         obj = os.path.join(objdir, "%s%s%s.o" % (src[:-4], suffix, tag))
         objs.append(obj)
-        if not (os.path.exists(obj) and os.path.getmtime(obj) >= newest):
-            todo.append([hipcc] + cflags + uflags + ["-c", os.path.join(CSRC, src), "-o", obj])
+        if not os.path.exists(obj):
+            # compile to a temporary name: an interrupted compile leaves no object that looks finished
+            todo.append((obj, [hipcc] + cflags + uflags + ["-c", os.path.join(CSRC, src), "-o", obj + ".part"]))
     running = []
     while todo or running:
         while todo and len(running) < JOBS:
-            cmd = todo.pop(0)
+            obj, cmd = todo.pop(0)
             if verbose:
                 print(" ".join(cmd), flush=True)
-            running.append((cmd, subprocess.Popen(cmd)))
-        cmd, p = running.pop(0)
+            running.append((obj, cmd, subprocess.Popen(cmd)))
+        obj, cmd, p = running.pop(0)
         if p.wait() != 0:
-            for _, q in running:
+            for _, _, q in running:
                 q.kill()
             raise subprocess.CalledProcessError(p.returncode, cmd)
+        os.replace(obj + ".part", obj)
     return hipcc, objs
+
+
+def _link(hipcc, objs, out, verbose=False):
+    """Link to a temporary file and rename it into place: a concurrent CDLL never sees a half-written library."""
+    tmp = "%s.%d.tmp" % (out, os.getpid())
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", tmp]
+    if verbose:
+        print(" ".join(link))
+    subprocess.check_call(link)
+    os.replace(tmp, out)
 
 
 def build_variant(name, extra_flags, verbose=False, layers=(3,), tangent=False):
@@ -87,26 +122,32 @@ def build_variant(name, extra_flags, verbose=False, layers=(3,), tangent=False):
     units = [u for u in UNITS if not u[2] or int(u[2][1:]) in layers]
     if not tangent:
         units = [u for u in units if u[0] != "lgar_tangent_nl.hip"]
-    flags = list(extra_flags) + ["-DLGAR_ONLY_LAYERS=%s" % "".join(str(n) for n in layers)] + ([] if tangent else ["-DLGAR_NO_TANGENT"])
-    hipcc, objs = _compile_all(units, os.path.join(vdir, "obj"), "_" + name, flags, verbose)
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out])
-    _stamp(out, extra_flags)
+    # -DLGAR_MEASURE: the measurement points of the device code take their definitions from csrc/lgar_measure.hpp
+    flags = list(extra_flags) + ["-DLGAR_MEASURE", "-DLGAR_ONLY_LAYERS=%s" % "".join(str(n) for n in layers)] + \
+            ([] if tangent else ["-DLGAR_NO_TANGENT"])
+    with _locked(out):
+        if not _stale(out, extra_flags):
+            return out
+        hipcc, objs = _compile_all(units, os.path.join(vdir, "obj_" + name), "", flags, verbose)
+        _link(hipcc, objs, out, verbose)
+        _stamp(out, extra_flags)
     return out
 
 
 def build(force=False, verbose=False):
     """Compile csrc/*.hip -> csrc/liblgar_hip.so.  hipcc cross-compiles gfx950 without a GPU.  The translation units
     (C-ABI, probe, and one per soil-layer count for the forward and the tangent kernels) are compiled concurrently into
-    csrc/obj/ and then linked."""
+    csrc/obj/<fingerprint>/ and then linked.  Safe to call from several processes at once (file lock; the library is renamed
+    into place)."""
     if not force and not _stale():
         return LIB
-    objdir = os.path.join(CSRC, "obj")
-    if force and os.path.isdir(objdir):
-        shutil.rmtree(objdir)
-    hipcc, objs = _compile_all(UNITS, objdir, "", [], verbose)
-    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB]
-    if verbose:
-        print(" ".join(link))
-    subprocess.check_call(link)
-    _stamp(LIB)
+    with _locked(LIB):
+        if not force and not _stale():  # another process built it while this one waited for the lock
+            return LIB
+        objroot = os.path.join(CSRC, "obj")
+        if force and os.path.isdir(objroot):
+            shutil.rmtree(objroot)
+        hipcc, objs = _compile_all(UNITS, objroot, "", [], verbose)
+        _link(hipcc, objs, LIB, verbose)
+        _stamp(LIB)
     return LIB

@@ -41,11 +41,7 @@ template <typename S> using real_t = typename Real<S>::type;
 
 __device__ __forceinline__ double val(double x) { return x; }
 __device__ __forceinline__ float val(float x) { return x; }
-#ifdef LGAR_F64_LIBM
-__device__ __forceinline__ double pw(double x, double y) { return pow(x, y); }  // ocml, < 1 ulp, ~200 instructions
-#else
 __device__ __forceinline__ double pw(double x, double y) { return fast_pow(x, y); }  // lgar_math.hpp, ~1e-14 relative
-#endif
 // fp32: v_log_f32 / v_exp_f32 (quarter-rate transcendentals), ~2-3 ulp for the exponents used here
 // log2 / exp2 (fused Geff node, dual-number pow)
 #ifndef LGAR_DEVSIM
@@ -89,23 +85,13 @@ template <int POL> __device__ __forceinline__ float dv(float a, float b) {
   return a / b;
 }
 template <int POL> __device__ __forceinline__ double dv(double a, double b) { return a / b; }
-#ifdef LGAR_F64_LIBM
-__device__ __forceinline__ double lg2(double x) { return log2(x); }
-__device__ __forceinline__ double ex2(double x) { return exp2(x); }
-#else
 __device__ __forceinline__ double lg2(double x) { return fast_log2(x); }
 __device__ __forceinline__ double ex2(double x) { return fast_exp2(x); }
-#endif
 // log2 / exp2 of arguments known to be positive / not NaN (the interior of the Geff trapezoid): no special-case selects
 __device__ __forceinline__ float lg2p(float x) { return lg2(x); }
 __device__ __forceinline__ float ex2p(float x) { return ex2(x); }
-#ifdef LGAR_F64_LIBM
-__device__ __forceinline__ double lg2p(double x) { return log2(x); }
-__device__ __forceinline__ double ex2p(double x) { return exp2(x); }
-#else
 __device__ __forceinline__ double lg2p(double x) { return fast_log2_core(x); }
 __device__ __forceinline__ double ex2p(double x) { return fast_exp2_core<false>(x); }
-#endif
 __device__ __forceinline__ double sq(double x) { return sqrt(x); }
 __device__ __forceinline__ double ab(double x) { return fabs(x); }
 __device__ __forceinline__ float ab(float x) { return fabsf(x); }
@@ -114,12 +100,19 @@ __device__ __forceinline__ float mn(float a, float b) { return fminf(a, b); }
 __device__ __forceinline__ bool is_nan(double x) { return x != x; }
 __device__ __forceinline__ bool is_nan(float x) { return x != x; }
 
-// Cost attribution by duplication (tools/ablate.py builds variants with -DLGAR_DUP_<X>): the named routine runs twice
-// on opaque copies of its inputs, results unchanged, so the time difference to the plain build is that routine's cost
-// with the column dynamics (and therefore all other work) untouched.
-#ifndef LGAR_DEVSIM
-__device__ __forceinline__ float opaque(float x) { asm volatile("" : "+v"(x)); return x; }
-__device__ __forceinline__ double opaque(double x) { asm volatile("" : "+v"(x)); return x; }
+// Measurement points (cost attribution, tools/ablate.py): LGAR_MEASURE_POINT(NAME, args) marks a place where a measurement
+// build can run a routine twice or count something, LGAR_ABLATABLE(NAME, statement) a statement such a build can leave out.
+// In the product both are transparent: the point is empty, the statement is just the statement.  Only
+// lgar_py_amd.build.build_variant passes -DLGAR_MEASURE, which takes the definitions from lgar_measure.hpp instead.
+#ifdef LGAR_MEASURE
+#include "lgar_measure.hpp"
+#else
+#define LGAR_MEASURE_POINT(NAME, ...)
+#define LGAR_ABLATABLE(NAME, ...) __VA_ARGS__
+// one lane per wave-level Geff evaluation adds 1 above the fault bits of its status word (no register, no LDS word; summed
+// over the wave at the end of the block): bits 8..31 are otherwise unused while a column is integrated
+#define LGAR_COUNT_GEFF_CALL(site) \
+  if (count_geff && first_active_lane()) status += (1 << LGAR_ST_STEP_SHIFT);
 #endif
 
 // tolerances: the reference's absolute 1e-12 (layers/Layer.py:60) is unreachable in fp32
@@ -260,7 +253,6 @@ template <typename S> __device__ __forceinline__ S geff(const LayerK<S> &l, S th
 // anyway.)  fp64 keeps the reference's running sum h2 += dh; a float instantiation would place the nodes directly
 // (h_i + (i+1) dh, last node = h_f): its running sum drifts by ~nint ulps of h_i, cm-scale for very dry soil, and the last
 // trapezoid dominates the integral.  The plain-float kernels use the packed loop further down instead.
-#ifndef LGAR_NO_FUSED_GEFF
 // K(h) of one trapezoid node, fused (see above); nm1 = n - 1, half_m = -m/2.  lgar_dual.hpp overloads it for dual numbers
 // (same value operations, hand-derived tangent).
 template <typename S> __device__ __forceinline__ S geff_node(const LayerK<S> &l, const S &nm1, const S &half_m, const S &h) {
@@ -287,8 +279,44 @@ __device__ __forceinline__ void geff_block8(const LayerK<S> &l, const S &nm1, co
     h2 = h2 + dh;
   }
 }
+#ifndef LGAR_DEVSIM
+// The trapezoid's interior for COOPERATING lanes (forward kernels on jobs too small to fill the chip, LgarDims.forward_lanes):
+// the `lanes` lanes of an aligned group all carry the SAME column -- same values, same branches -- so node j is evaluated by
+// lane j mod lanes only, left in the wave's LDS buffer, and every lane then adds the nodes up in order.  Heads, node values
+// and the sum are those of the plain loop bit for bit: each node goes through the same operations on the same operands
+// (h2 by the same repeated addition), only once per group instead of once per lane.
+__device__ __forceinline__ void geff_nodes_cooperative(const LayerK<double> &l, double nm1, double half_m, double k_sat1, double &h2,
+                                                       double dh, double hdh, double &g, double &k1, int nint, int lanes, double *xchg) {
+  const int lane = (int)(threadIdx.x & 63u);
+  const int r = lane & (lanes - 1);
+  double *grp = xchg + (lane & ~(lanes - 1));
+  for (int i0 = 0; i0 < nint; i0 += lanes) {
+    const int cnt = (nint - i0 < lanes) ? nint - i0 : lanes;
+    // the heads of this round by the running sum of the plain loop; mine is number r
+    double hm = h2;
+    for (int q = 0; q < cnt; q++) {
+      hm = (q == r) ? h2 : hm;
+      h2 = h2 + dh;
+    }
+    double k2 = geff_node(l, nm1, half_m, hm);
+    k2 = (fabs(hm) < 0.1 || hm < 0.0) ? k_sat1 : k2;  // utils.py:124-128 (never true on the nodes the plain loop leaves unchecked)
+    // one wave = one workgroup: LDS operations of a wave complete in order, the fences only pin the compiler
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    grp[r] = k2;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    for (int q = 0; q < cnt; q++) {
+      const double kq = grp[q];  // same address in every lane of the group: an LDS broadcast
+      g = g + ((k1 + kq) * hdh);
+      k1 = kq;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // the next round's stores stay behind these loads
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+#endif
 template <typename S>
-__device__ __forceinline__ S geff_fused(const LayerK<S> &l, S theta1, S theta2, int nint, real_t<S> *xchg = nullptr) {
+__device__ __forceinline__ S geff_fused(const LayerK<S> &l, S theta1, S theta2, int nint, real_t<S> *xchg = nullptr, int coop = 0) {
   using R = real_t<S>;
   const S se_i = se_from_theta(l, theta1);
   const S se_f = se_from_theta(l, theta2);
@@ -321,7 +349,14 @@ __device__ __forceinline__ S geff_fused(const LayerK<S> &l, S theta1, S theta2, 
     if (xchg != nullptr)
       for (; i + 7 < n_safe; i += 8) geff_block8(l, nm1, half_m, h2, dh, hdh, g, k1, xchg);
   }
-#ifndef LGAR_NO_FUSED_PAIR
+#ifndef LGAR_DEVSIM
+  if constexpr (sizeof(S) == 8 && sizeof(R) == 8) {
+    if (coop > 1 && xchg != nullptr) {
+      geff_nodes_cooperative(l, nm1, half_m, k_sat1, h2, dh, hdh, g, k1, nint, coop, xchg);
+      i = nint;
+    }
+  }
+#endif
   // fp64 and its dual numbers: two nodes per iteration give the scheduler two independent chains (same sums in the same
   // order; measured: backward -1.5 %, fp64 forward -1 %, a job of 157 waves -3 %)
   if constexpr (sizeof(R) == 8) {
@@ -335,7 +370,6 @@ __device__ __forceinline__ S geff_fused(const LayerK<S> &l, S theta1, S theta2, 
       h2 = hb + dh;
     }
   }
-#endif
   for (; i < n_safe; i++) {
     if (sizeof(R) == 4) h2 = (i + 1 >= nint) ? h_f : h_i + R(i + 1) * dh;
     const S k2 = node(h2);
@@ -369,7 +403,6 @@ __device__ __forceinline__ S geff_fused(const LayerK<S> &l, S theta1, S theta2, 
 // dh/2 (K_0 + K_n + 2 sum of interior nodes): one packed add per node pair.  Interior nodes sit at h_i + j dh (no running
 // sum: it drifts by cm for very dry soil); the last node is h_f itself, which dominates the integral for dry soil.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-#ifndef LGAR_NO_PACKED_GEFF
 template <> __device__ __forceinline__ float geff<float>(const LayerK<float> &l, float theta1, float theta2, int nint) {
   const float se_i = se_from_theta(l, theta1);
   const float se_f = se_from_theta(l, theta2);
@@ -476,16 +509,9 @@ template <> __device__ __forceinline__ float geff<float>(const LayerK<float> &l,
   const float k0 = node(x0), kn = node(l.alpha * h_f);
   return fabsf((0.5f * dh) * ((k0 + kn) + 2.0f * sum));
 }
-#else
-template <> __device__ __forceinline__ float geff<float>(const LayerK<float> &l, float t1, float t2, int nint) {
-  return geff_fused<float>(l, t1, t2, nint);
-}
-#endif
-#ifndef LGAR_LITERAL_GEFF_F64
 template <> __device__ __forceinline__ double geff<double>(const LayerK<double> &l, double t1, double t2, int nint) {
   return geff_fused<double>(l, t1, t2, nint);
 }
-#endif
 
 // Mixed-precision Geff (LgarDims.geff_mode = 1, fp64 runs): the column state, every branch and the mass bookkeeping stay
 // in double precision; of the trapezoid, only the 119 INTERIOR nodes are evaluated with the fp32 hardware transcendentals.
@@ -515,8 +541,7 @@ __device__ __forceinline__ double geff_mixed(const LayerK<double> &l, double the
   const double dh = (h_f - h_i) / double(nint);
   const double x0 = l.alpha * h_i, dx = l.alpha * dh, xcut = 0.1 * l.alpha;
   // exponents as fp32 pairs
-  const double nm1d = l.n - 1.0, hmd = -0.5 * l.m;
-  const float nm1 = (float)nm1d, nm1_lo = (float)(nm1d - (double)nm1);
+  const double hmd = -0.5 * l.m;
   const float hm = (float)hmd, hm_lo = (float)(hmd - (double)hm);
   // K_r at Se == 1 (the 1e-12 nudge of calc_k_from_se): (1 - (1e-12)^m)^2
   const double tsat = 1.0 - ex2p(l.m * -39.863137138648355);
@@ -536,19 +561,43 @@ __device__ __forceinline__ double geff_mixed(const LayerK<double> &l, double the
     }
   }
   const float xcutf = (float)xcut;
-  const f32x2 nm12 = {nm1, nm1}, nm1l2 = {nm1_lo, nm1_lo}, hm2 = {hm, hm}, hml2 = {hm_lo, hm_lo}, one2 = {1.0f, 1.0f};
+  const float nf = (float)l.n, nf_lo = (float)(l.n - (double)nf), mmf = (float)(-l.m), mmf_lo = (float)(-l.m - (double)mmf);
+  const f32x2 n2 = {nf, nf}, nl2 = {nf_lo, nf_lo}, hm2 = {hm, hm}, hml2 = {hm_lo, hm_lo}, one2 = {1.0f, 1.0f}, two2 = {2.0f, 2.0f};
+  const f32x2 ln2_2 = {0.693147181f, 0.693147181f}, c2_2 = {0.5f, 0.5f}, c3_2 = {1.0f / 6.0f, 1.0f / 6.0f};
+  const f32x2 c4_2 = {1.0f / 24.0f, 1.0f / 24.0f}, c5_2 = {1.0f / 120.0f, 1.0f / 120.0f};
+  const f32x2 mm2 = {mmf, mmf}, mml2 = {mmf_lo, mmf_lo}, ilog2 = {1.44269504f, 1.44269504f};
   // one node pair: sqrt(Se) and (1 - P Se)^2 of the nodes at X.x, X.y
 #define LGAR_GEFFM_PAIR(X, SR, TT)                                                          \
   {                                                                                         \
-    f32x2 lg, P, l1;                                                                        \
+    /* log2 a = n log2 x;  r = 1/a;  L = log2(1 + r) from c = fl(1 + r), compensated for the rounding of the sum  */ \
+    f32x2 lg, r, Lc;                                                                        \
     lg.x = lg2((X).x); lg.y = lg2((X).y);                                                   \
-    const f32x2 e0 = __builtin_elementwise_fma(nm12, lg, nm1l2 * lg);                       \
-    P.x = ex2(e0.x); P.y = ex2(e0.y);                                                       \
-    const f32x2 opa = __builtin_elementwise_fma((X), P, one2);                              \
-    l1.x = lg2(opa.x); l1.y = lg2(opa.y);                                                   \
+    const f32x2 la = __builtin_elementwise_fma(n2, lg, nl2 * lg);                           \
+    r.x = ex2(-la.x); r.y = ex2(-la.y);                                                     \
+    const f32x2 c = one2 + r;                                                               \
+    const f32x2 rho = r - (c - one2);                                                       \
+    Lc.x = lg2(c.x); Lc.y = lg2(c.y);                                                       \
+    f32x2 ic = two2 - c; /* ~ 1/c where the correction matters (c near 1); nothing for c >= 2 */ \
+    ic.x = fmaxf(ic.x, 0.0f); ic.y = fmaxf(ic.y, 0.0f);                                     \
+    const f32x2 L = __builtin_elementwise_fma(rho * ic, ilog2, Lc);                         \
+    /* sqrt(Se) = (1 + a)^(-m/2) = 2^(-m/2 (log2 a + L)) */                                 \
+    const f32x2 l1 = la + L;                                                                \
     const f32x2 e1 = __builtin_elementwise_fma(hm2, l1, hml2 * l1);                         \
     (SR).x = ex2(e1.x); (SR).y = ex2(e1.y);                                                 \
-    const f32x2 t = __builtin_elementwise_fma(-P, (SR) * (SR), one2);                       \
+    /* t = 1 - (a/(1+a))^m = 1 - 2^E with E = -m L.  Dry nodes have 2^E -> 1: there t = -expm1(E ln 2) by its series  \
+       (5 terms for 2^E > 7/8), not by the cancelling difference */                         \
+    const f32x2 E = __builtin_elementwise_fma(mm2, L, mml2 * L);                            \
+    f32x2 w;                                                                                \
+    w.x = ex2(E.x); w.y = ex2(E.y);                                                         \
+    const f32x2 y = E * ln2_2;                                                              \
+    f32x2 p = __builtin_elementwise_fma(c5_2, y, c4_2);                                     \
+    p = __builtin_elementwise_fma(p, y, c3_2);                                              \
+    p = __builtin_elementwise_fma(p, y, c2_2);                                              \
+    p = __builtin_elementwise_fma(p, y, one2);                                              \
+    const f32x2 ts = -y * p;                                                                \
+    f32x2 t = one2 - w;                                                                     \
+    t.x = (w.x > 0.875f) ? ts.x : t.x;                                                      \
+    t.y = (w.y > 0.875f) ? ts.y : t.y;                                                      \
     (TT) = t * t;                                                                           \
   }
   double acc = 0.0, accb = 0.0;  // node pairs with even / odd index
@@ -592,12 +641,12 @@ __device__ __forceinline__ double geff_mixed(const LayerK<double> &l, double the
   // end nodes in double precision, with the reference's own formulas (|h| < 0.1 -> Se = 1 applies to the LAST node only:
   // the first node's K is calc_k_from_se(Se_i) as it stands, green_ampt.py:60)
   const double k0 = kr_from_se(l, se_i);
-  const double kn = (fabs(h_f) < 0.1 || h_f < 0.0) ? ksat1 : kr_from_se(l, se_from_h<double, 0>(l, h_f));
+  // (the last node's Se is Se(h(Se_f)) in the reference: Se_f up to the rounding of the round trip)
+  const double kn = (fabs(h_f) < 0.1 || h_f < 0.0) ? ksat1 : kr_from_se(l, se_f);
   const double res = fabs((0.5 * dh) * ((k0 + kn) + 2.0 * sum));
   const bool outside = is_nan(h_i) || is_nan(h_f);
   return outside ? res + (h_i + h_f) : res;
 }
-#endif
 // calc_geff with use_closed_form_G (lgar/green_ampt.py:85-98): Brooks-Corey estimate from the van Genuchten parameters
 // (calc_bc_lambda / calc_bc_psib, physics/utils.py:54-64, 84-99).  Operator precedence as written in the reference:
 // geff = h_c * Se_i^e - Se_f^e / (1 - Se_f^e), with Se_f from theta_1 and Se_i from theta_2; inf/nan -> h_c.
@@ -671,6 +720,7 @@ template <typename S, int FMAX> struct FrontsView {
 // MODE 0: the reference's literal line searches, its update_psi pass and per-sub-step NaN scan.
 // MODE 1 (default of the engine, what bench.py measures): the same roots by bracketed Newton / closed-form jumps; the
 // passes that are provably no-ops between events are skipped (see forward()).
+// MODE 3 (double precision only, LgarDims.geff_mode = 1): MODE 1 with the mixed-precision trapezoid (geff_mixed).
 template <typename S, int NL, int FMAX, int MODE> struct Column {
   using R = real_t<S>;
   // arithmetic policy (see dv / pwx): verification mode in double precision uses the library pow (the reference's
@@ -690,8 +740,9 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
   S k_deepest;
   bool new_front_frozen;
   bool count_geff = false;              // measurement: count wave-level Geff evaluations in the unused upper bits of `status`
-  int share_lanes = 0;                  // tangent kernels: 8 = my seven neighbours carry this same column (other directions)
-  R *xchg = nullptr;                    // ... and the wave's [5][64] LDS buffer they exchange trapezoid nodes through
+  int share_lanes = 0;                  // tangent kernels: 8 = my seven neighbours carry this same column (other directions);
+                                        // forward kernels: 2..64 = that many adjacent lanes carry this very column (small jobs)
+  R *xchg = nullptr;                    // ... and the wave's LDS buffer they exchange trapezoid nodes through
   int cap = FMAX;                       // fronts this column may hold: min(kernel capacity, rows of the state arrays)
   // accumulators drained every forcing step (physics/MassBalance.py:45-53)
   S a_precip, a_pet, a_aet, a_infil, a_runoff, a_perc, a_giuh, a_disch;
@@ -702,39 +753,22 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
   // calc_geff (lgar/green_ampt.py:19-99): trapezoid or closed form, per cfg.data.use_closed_form_G
   __device__ __forceinline__ S capillary_drive(const LayerK<S> &lk, S theta1, S theta2, int site = 0) {
     (void)site;
-#ifdef LGAR_ABL_NOGEFF  // register-pressure experiments (tools/): what the allocator does without the trapezoid
-    return theta1 * theta2 + lk.alpha;
-#endif
-    // one lane per wave-level evaluation adds 1 above the fault bits (no register, no LDS word; summed over the wave at the
-    // end of the block): bits 8..31 of status are otherwise unused while a column is integrated
-#ifdef LGAR_COUNT_SITE  // measurement variants (tools/ablate.py): count one call site only (1 dzdt, 2 dry depth, 3 insert)
-    if (site == LGAR_COUNT_SITE)
-#endif
-#ifdef LGAR_COUNT_MAXLANES  // ... and only the evaluations with at most this many lanes taking part
-    if (__builtin_popcountll(any_lane(true)) <= LGAR_COUNT_MAXLANES)
-#endif
-    {
-#ifdef LGAR_COUNT_LANES  // measurement variant: every evaluating lane counts
-      if (count_geff) status += (1 << LGAR_ST_STEP_SHIFT);
-#else
-      if (count_geff && first_active_lane()) status += (1 << LGAR_ST_STEP_SHIFT);
-#endif
-    }
-#ifdef LGAR_DUP_GEFF
-    if constexpr (sizeof(S) == sizeof(R)) {
-      const S extra = geff(lk, opaque(theta1), opaque(theta2), G->nint);
-      if (val(extra) == R(12345.678)) return extra;  // practically never true: keeps the duplicate alive
-    }
-#endif
+    LGAR_MEASURE_POINT(NOGEFF, lk, theta1, theta2)
+    LGAR_COUNT_GEFF_CALL(site)
+    LGAR_MEASURE_POINT(DUP_GEFF, lk, theta1, theta2)
     if constexpr (MODE == 0 && sizeof(R) == 8) {
       // verification mode: the reference's trapezoid operation by operation (4 pow + sqrt per node, running h)
       return G->closed_form ? geff_closed<S, POL>(lk, theta1, theta2) : geff_literal<S, POL>(lk, theta1, theta2, G->nint);
     }
-#ifndef LGAR_NO_FUSED_GEFF
     if constexpr (sizeof(S) != sizeof(R) && sizeof(R) == 8 && MODE != 0) {
       if (share_lanes == 8 && !G->closed_form) return geff_fused<S>(lk, theta1, theta2, G->nint, xchg);
     }
-#endif
+    if constexpr (MODE == 1 && sizeof(S) == 8 && sizeof(R) == 8) {  // plain double: cooperating lanes (small jobs)
+      if (share_lanes > 1 && !G->closed_form) return geff_fused<S>(lk, theta1, theta2, G->nint, xchg, share_lanes);
+    }
+    if constexpr (MODE == 3 && sizeof(S) == 8 && sizeof(R) == 8) {  // plain double, LgarDims.geff_mode = 1
+      if (!G->closed_form) return geff_mixed(lk, theta1, theta2, G->nint);
+    }
     return G->closed_form ? geff_closed<S, POL>(lk, theta1, theta2) : geff(lk, theta1, theta2, G->nint);
   }
   __device__ __forceinline__ S cum_prev(int k) const {  // cum[k-1], 0 for k == 0
@@ -878,9 +912,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
     R delta_mass_prev = delta_mass;
     int count_no_change = 0;
     if (delta_mass <= Tol<R>::mass) return theta_from_h<S, POL>(lk, psi);
-#ifdef LGAR_ABL_NOSEARCH
-    return theta_from_h<S, POL>(lk, psi + new_mass);
-#endif
+    LGAR_MEASURE_POINT(NOSEARCH, lk, psi, new_mass)
     if constexpr (MODE != 0) return theta_mass_balance_newton<K>(lk, psi, new_mass, prior_mass, dth, dthick, dth_k, dthick_k);
     long long it = 0;
     while (delta_mass > Tol<R>::mass) {
@@ -1034,12 +1066,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
           const S t_dth_k = F.TH(i + 1);
           const S t_dthick_k = z - prev_thick;
           if (i == c.fdd || feq(c.fdd, i)) prior_mass = prior_mass + c.infiltration - (R(0.0) + c.aet);
-#ifdef LGAR_DUP_SEARCH
-          if constexpr (sizeof(S) == sizeof(R)) {
-            const S extra = theta_mass_balance<K>(lk, opaque(psi), opaque(new_mass), opaque(prior_mass), dth, dthick, t_dth_k, t_dthick_k);
-            if (val(extra) == R(-1.0)) status |= LGAR_ST_STRUCT;  // never true
-          }
-#endif
+          LGAR_MEASURE_POINT(DUP_SEARCH, K, lk, psi, new_mass, prior_mass, dth, dthick, t_dth_k, t_dthick_k)
           S theta_new = theta_mass_balance<K>(lk, psi, new_mass, prior_mass, dth, dthick, t_dth_k, t_dthick_k);
           F.TH(i) = mn(theta_new, lk.te);
           need_psi = true;
@@ -1267,10 +1294,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
     move_sweep(infiltration, aet, old_mass, fdd);
     S bottom_flux = S(R(0.0));
     // (a per-lane decision: a column's results must not depend on which other columns share its wave)
-#ifdef LGAR_DUP_EVENT
-    if (front_event_pending() && val(F.Z(0)) == R(-12345.0)) status |= LGAR_ST_STRUCT;  // never true
-    asm volatile("" ::: "memory");
-#endif
+    LGAR_MEASURE_POINT(DUP_EVENT)
     if (__builtin_expect(front_event_pending(), 0)) {
       for (int pass = 0; pass < 2; pass++) {
         merge_fronts();
@@ -1288,10 +1312,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
     // from (a layer's deepest front), so the pass only adds a theta -> psi -> theta round trip: MODE 0 keeps it, MODE 1
     // runs it only after an event.
     if constexpr (MODE == 0) update_psi();
-#ifdef LGAR_DUP_PSI
-    asm volatile("" ::: "memory");
-    update_psi();
-#endif
+    LGAR_MEASURE_POINT(DUP_PSI)
     return bottom_flux;
   }
 
@@ -1468,10 +1489,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
       S ponded_water_sub = S(R(0.0)), runoff_sub = S(R(0.0)), infiltration_sub = S(R(0.0)), AET_sub = S(R(0.0));
       // create_surficial_front predicate, models/dpLGAR.py:310-323
       const bool create = (val(previous_precip) == R(0.0)) && (val(precip_sub) > R(0.0)) && (val(ponded_water) == R(0.0));
-#ifdef LGAR_DUP_FDD
-      if (free_drainage_front() == 12345) status |= LGAR_ST_STRUCT;  // never true
-      asm volatile("" ::: "memory");
-#endif
+      LGAR_MEASURE_POINT(DUP_FDD)
       const int fdd = free_drainage_front();
       const bool saturated = val(F.TH(0)) >= val(P.te[0]);  // Layer.is_saturated, Layer.py:785-793
       if (val(pet) > R(0.0)) AET_sub = aet_fn<S, POL>(pick_static(P, 0), pet, dt, F.PS(0), G->wp_psi);
@@ -1483,19 +1501,16 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
       // after the move is equivalent.
       const bool inserting = !create && val(ponded_depth_sub) > R(0.0);
       if (inserting) {
-#ifndef LGAR_ABL_NOINSERT
-        insert_water(fdd, precip_sub, ponded_depth_sub, infiltration_sub, runoff_sub);
-#endif
+        LGAR_ABLATABLE(INSERT, insert_water(fdd, precip_sub, ponded_depth_sub, infiltration_sub, runoff_sub);)
         a_infil = a_infil + infiltration_sub;
         a_runoff = a_runoff + runoff_sub;
         ponded_water_sub = ponded_depth_sub;
       }
-#ifndef LGAR_ABL_NOMOVE
       if (!create || !saturated) {
-        S perc_sub = move_wetting_front(create ? S(R(0.0)) : infiltration_sub, AET_sub, ending_volume_sub, fdd);
+        S perc_sub = S(R(0.0));
+        LGAR_ABLATABLE(MOVE, perc_sub = move_wetting_front(create ? S(R(0.0)) : infiltration_sub, AET_sub, ending_volume_sub, fdd);)
         if (!create) a_perc = a_perc + perc_sub;
       }
-#endif
       if (__builtin_expect(create && !saturated, 0)) {
         S dry_depth = calc_dry_depth();
         create_surficial_front(dry_depth, ponded_depth_sub, infiltration_sub);
@@ -1514,18 +1529,9 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
           a_runoff = a_runoff + runoff_sub;
         }
       }
-#ifndef LGAR_ABL_NODZDT
-      calc_dzdt(ponded_depth_sub);
-#endif
-#ifdef LGAR_DUP_DZDT
-      asm volatile("" ::: "memory");
-      calc_dzdt(ponded_depth_sub);  // idempotent: a second pass recomputes the same dz/dt (Geff included)
-#endif
-#ifdef LGAR_DUP_MB
-      ending_volume_sub = mass_balance();
-      asm volatile("" ::: "memory");
-      if (val(ending_volume_sub) == R(-1.0)) status |= LGAR_ST_STRUCT;  // never true
-#endif
+      LGAR_ABLATABLE(DZDT, calc_dzdt(ponded_depth_sub);)
+      LGAR_MEASURE_POINT(DUP_DZDT, ponded_depth_sub)
+      LGAR_MEASURE_POINT(DUP_MB, ending_volume_sub)
       ending_volume_sub = mass_balance();
       previous_precip = precip_sub;
       ending_volume = ending_volume_sub;

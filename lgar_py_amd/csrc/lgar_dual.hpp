@@ -98,7 +98,6 @@ template <typename R> __device__ __forceinline__ Dual<R> ex2p(const Dual<R> &y) 
   const R v = ex2p(y.v);
   return Dual<R>(v, v * R(0.6931471805599453) * y.d);
 }
-#if !defined(LGAR_NO_FUSED_GEFF) && !defined(LGAR_GENERIC_DUAL_NODE)
 // The fused Geff node for dual numbers: the value is computed by the same operations in the same order as the plain node
 // (lgar_device.hpp geff_node), the tangent in logarithmic form -- with a = x P, A = 1 + a, s = A^(-m/2), t = 1 - P s^2:
 //   dln x = dx / x,  dln P = d(n-1) ln x + (n-1) dln x,  dln A = (a / A)(dln x + dln P),  dln s = d(-m/2) ln A - (m/2) dln A,
@@ -129,8 +128,7 @@ __device__ __forceinline__ Dual<R> geff_node(const LayerK<Dual<R>> &l, const Dua
   const R Kd = l.ksat.d * (sv * tt) + Kv * dlns + (R(2.0) * (ks * tv)) * dt;
   return Dual<R>(Kv, Kd);
 }
-#endif
-#if !defined(LGAR_NO_FUSED_GEFF) && !defined(LGAR_GENERIC_DUAL_NODE) && !defined(LGAR_DEVSIM)
+#ifndef LGAR_DEVSIM
 // Eight nodes for eight lanes that integrate the SAME column along eight parameter directions (autograd.parameter_vjp lays
 // them side by side, LgarDims.tangent_share): the values -- and with them every branch -- are identical in the eight lanes,
 // only the tangents differ.  Lane r evaluates node r of an eight-node block and leaves the result in the wave's LDS buffer; every
@@ -207,7 +205,6 @@ __device__ __forceinline__ void geff_block8(const LayerK<Dual<double>> &l, const
   h2 = h[7] + dh;
 }
 #endif
-#ifndef LGAR_NO_FUSED_GEFF
 template <> __device__ __forceinline__ Dual<double> geff<Dual<double>>(const LayerK<Dual<double>> &l, Dual<double> t1,
                                                                        Dual<double> t2, int nint) {
   return geff_fused<Dual<double>>(l, t1, t2, nint);
@@ -216,6 +213,5 @@ template <> __device__ __forceinline__ Dual<float> geff<Dual<float>>(const Layer
                                                                      Dual<float> t2, int nint) {
   return geff_fused<Dual<float>>(l, t1, t2, nint);
 }
-#endif
 
 }  // namespace lgar

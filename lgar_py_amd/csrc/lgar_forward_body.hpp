@@ -18,6 +18,7 @@ namespace lgar {
 template <typename R> struct KArgs {
   int N, T, F;                                            // columns, forcing steps, rows of the per-front state arrays
   int Nf, Fg;                                             // forcing columns and group: column c reads forcing column (c / Fg) % Nf
+  int coop;                                               // lanes per column (1, or 2..64: cooperating lanes, small jobs)
   unsigned *ticket;                                       // null, or the work counter of this launch (persistent waves)
   int chain_first, chain_last;                            // position in the capacity chain (see above)
   const unsigned *pending_in;                             // null, or how many columns the previous kernel of the chain handed over
@@ -155,9 +156,12 @@ __device__ __forceinline__ void init_lane(const LGAR_KARG KArgs<R> *ap, size_t c
 // T x (dpLGAR.forward + MassBalance.change_mass) for one column; the time loop is inside.
 // `live` = false for the padding lanes of a ragged tail wave: they integrate a copy of the last column (all 64 lanes stay
 // active for the wave reductions) and store nothing.
+// Cooperating lanes (a.coop = 2..64, jobs too small to fill the chip): that many adjacent lanes integrate the SAME column c
+// redundantly -- same loads, same values, same branches -- and split the nodes of the Geff trapezoid between them (xchg: the
+// wave's exchange buffer); `leader` is true for the one lane of the group that stores the column's results.
 template <typename R, int NL, int FMAX, int MODE>
 __device__ __forceinline__ void forward_lane(const LGAR_KARG KArgs<R> *ap, size_t c, bool live, int lane,
-                                             WaveLDS<R, FMAX> &lds) {
+                                             WaveLDS<R, FMAX> &lds, bool leader = true, R *xchg = nullptr) {
   const LGAR_KARG KArgs<R> &a = *ap;
   const size_t N = (size_t)a.N;
   const bool basin_on = (a.basin != nullptr) && (a.basin_mask != 0u);
@@ -199,6 +203,8 @@ __device__ __forceinline__ void forward_lane(const LGAR_KARG KArgs<R> *ap, size_
   col.new_front_frozen = false;
   col.cap = FMAX < a.F ? FMAX : a.F;
   col.count_geff = a.counters != nullptr;
+  col.share_lanes = (xchg != nullptr) ? a.coop : 0;
+  col.xchg = xchg;
   col.drain();
   // accumulators summed over the steps this kernel integrates: the first SR in LDS, the rest in registers
   constexpr int SR = LdsSums<R, FMAX>::rows;
@@ -209,7 +215,7 @@ __device__ __forceinline__ void forward_lane(const LGAR_KARG KArgs<R> *ap, size_
     if (j < SR) lds.sums[j][lane] = R(0);
   }
   double wgt = 0.0;
-  if (basin_on) wgt = a.weights ? (double)a.weights[c] : 1.0;
+  if (basin_on && leader) wgt = a.weights ? (double)a.weights[c] : 1.0;
 
   // the column is integrated for steps t_begin <= t < t_stop; t_stop < T: handed to the next kernel of the chain at
   // t_stop (or, t_stop = -1, stopped for good before its first step); t_stop <= t_begin: the state in HBM is left as it is
@@ -243,13 +249,11 @@ __device__ __forceinline__ void forward_lane(const LGAR_KARG KArgs<R> *ap, size_
     if (active) col.forward(precip, pet);
     const R acc[LGAR_NACC] = {col.a_precip, col.a_pet, col.a_aet, col.a_infil, col.a_runoff,
                               col.a_perc, col.a_giuh, col.a_disch, col.ponded_water, col.ending_volume};
-#ifndef LGAR_ABL_NOEPILOGUE
-    if (active) {
+    if (active && leader) {
 #pragma unroll
       for (int j = 0; j < LGAR_NACC; j++)
         if (a.series[j]) a.series[j][o] = acc[j];
     }
-#endif
     if (basin_on) {
       // basin aggregation in the epilogue of the step (physics/MassBalance.py:77-108 over many columns)
       const double w = active ? wgt : 0.0;
@@ -281,6 +285,7 @@ __device__ __forceinline__ void forward_lane(const LGAR_KARG KArgs<R> *ap, size_
   }
   col.status &= LGAR_ST_FAULT_MASK;
   if (t_begin >= z.T) return;  // not this kernel's column (or a padding lane)
+  if (!leader) return;  // the column's results are stored by the leader of its group of cooperating lanes
   if (z.pending_out != nullptr) {
     // columns handed to the next kernel of the chain are counted, so that a next kernel with nothing to do (the usual
     // case) leaves after one load instead of scanning every status word

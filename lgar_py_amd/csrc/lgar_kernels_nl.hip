@@ -11,6 +11,8 @@
 // scalars/totals, and per forcing step 2 loads + (number of requested series) stores per column.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "lgar_forward_body.hpp"
 #include "lgar_host.hpp"
 #include "lgar_launch.hpp"
@@ -42,9 +44,17 @@ __global__ __launch_bounds__(WAVE) void lgar_init_kernel(KArgs<R> a) {
   init_lane<R, NL, CAP>((const LGAR_KARG KArgs<R> *)__builtin_amdgcn_kernarg_segment_ptr(), c, lane, lds);
 }
 
+// LDS buffer through which cooperating lanes exchange trapezoid nodes (lgar_device.hpp geff_nodes_cooperative): only the
+// double-precision fast kernels have the mode; 8 front slots + sums + this = exactly 20 KiB per wave (8 waves per CU)
+template <typename R, int MODE> struct CoopLDS {
+  static constexpr bool on = (sizeof(R) == 8) && (MODE == 1);
+  R v[on ? WAVE : 1];
+};
+
 template <typename R, int NL, int CAP, int MODE>
 __global__ __launch_bounds__(WAVE, (Occupancy<R, CAP>::waves)) void lgar_forward_kernel(KArgs<R> a) {
   __shared__ WaveLDS<R, CAP> lds;
+  __shared__ CoopLDS<R, MODE> coop_lds;
   const int lane = threadIdx.x;
   // the argument block is read in place (kernarg segment), see LGAR_KARG in lgar_device.hpp
   const LGAR_KARG KArgs<R> *ap = (const LGAR_KARG KArgs<R> *)__builtin_amdgcn_kernarg_segment_ptr();
@@ -54,7 +64,9 @@ __global__ __launch_bounds__(WAVE, (Occupancy<R, CAP>::waves)) void lgar_forward
   // With a ticket counter: persistent waves.  The grid is one wave per wave slot of the chip; each pulls 64-column blocks
   // from the counter until none is left, so no round of the grid is partially filled whatever the column count.
   // Without: one workgroup per block.
-  const unsigned nblocks = (unsigned)((N + WAVE - 1) / WAVE);
+  // cooperating lanes: `coop` adjacent lanes per column (a power of two; 1 = every lane its own column)
+  const int coop = CoopLDS<R, MODE>::on ? ap->coop : 1;
+  const unsigned nblocks = (unsigned)((N * (size_t)coop + WAVE - 1) / WAVE);
   for (bool first = true;; first = false) {
     unsigned blk = blockIdx.x;
     if (ticket != nullptr) {
@@ -63,6 +75,14 @@ __global__ __launch_bounds__(WAVE, (Occupancy<R, CAP>::waves)) void lgar_forward
       if (blk >= nblocks) break;
     } else if (!first) {
       break;
+    }
+    if constexpr (CoopLDS<R, MODE>::on) {
+      if (coop > 1) {
+        const size_t c0 = ((size_t)blk * WAVE + lane) / (size_t)coop;
+        const bool live = c0 < N;
+        forward_lane<R, NL, CAP, MODE>(ap, live ? c0 : N - 1, live, lane, lds, (lane & (coop - 1)) == 0, &coop_lds.v[0]);
+        continue;
+      }
     }
     const size_t c0 = (size_t)blk * WAVE + lane;
     const bool live = c0 < N;
@@ -79,6 +99,7 @@ static KArgs<R> make_args(const LgarDims *d, const LgarParams *p, LgarState *s, 
   a.F = front_slots(d);
   a.Nf = forcing_columns(d);
   a.Fg = forcing_group(d);
+  a.coop = 1;
   a.ticket = nullptr;
   a.pending_in = nullptr;
   a.pending_out = nullptr;
@@ -126,12 +147,38 @@ static unsigned wave_slots(int waves) {
 template <typename R, int NL, int CAP, int MODE>
 static void launch_forward_kernel(KArgs<R> &a, unsigned nblocks, unsigned *ticket, hipStream_t st) {
   a.ticket = ticket;
+  if (!CoopLDS<R, MODE>::on) a.coop = 1;
+  nblocks = (unsigned)(((size_t)a.N * (size_t)a.coop + WAVE - 1) / WAVE);
   unsigned grid = nblocks;
   if (ticket != nullptr) {
     const unsigned slots = wave_slots(Occupancy<R, CAP>::waves);
     grid = nblocks < slots ? nblocks : slots;
   }
   hipLaunchKernelGGL((lgar_forward_kernel<R, NL, CAP, MODE>), dim3(grid), dim3(WAVE), 0, st, a);
+}
+
+// fast-mode kernel of capacity CAP: MODE 1, or -- double precision with LgarDims.geff_mode = 1 -- MODE 3 (mixed-precision
+// trapezoid, lgar_device.hpp geff_mixed)
+template <typename R, int NL, int CAP>
+static void launch_fast_kernel(KArgs<R> &a, unsigned nblocks, unsigned *ticket, hipStream_t st, bool mixed) {
+  if constexpr (sizeof(R) == 8) {
+    if (mixed) {
+      launch_forward_kernel<R, NL, CAP, 3>(a, nblocks, ticket, st);
+      return;
+    }
+  }
+  (void)mixed;
+  launch_forward_kernel<R, NL, CAP, 1>(a, nblocks, ticket, st);
+}
+
+// lanes per column for this job: LgarDims.forward_lanes when given, else the largest power of two <= 64 that keeps
+// n_columns * lanes / 64 waves within `slots` (1 for jobs that fill the chip anyway, for fp32, closed-form G, geff_mode 1)
+template <typename R> static int cooperating_lanes(const LgarDims *dims, unsigned slots) {
+  if (sizeof(R) != 8 || dims->search_mode == 0 || dims->use_closed_form_G || dims->geff_mode != 0) return 1;
+  if (dims->forward_lanes > 0) return dims->forward_lanes;
+  int lanes = 1;
+  while (lanes < WAVE && ((size_t)dims->n_columns * (size_t)(lanes * 2) + WAVE - 1) / WAVE <= (size_t)slots) lanes *= 2;
+  return lanes;
 }
 
 // The front-capacity chain of one lgar_forward call (see lgar_forward_body.hpp).
@@ -151,10 +198,17 @@ static int forward_typed(const LgarDims *dims, const LgarParams *params, LgarSta
   // smallest capacity that leaves room for a forcing step (one front per layer + one new front per sub-step + slack);
   // small jobs (under one wave per SIMD) gain nothing from occupancy and start at the full capacity
   const int need = NL + dims->num_subcycles + 2;
-  const bool tiny = grid <= 1024u && dims->search_mode != 2;  // search_mode 2: chain forced (tests)
+  // Jobs that cannot fill the chip (the reference's own use is ONE column, agents/DifferentiableLGAR.py:117-125; BASELINE
+  // configs[1] is 10 000): in double precision every column gets 2..64 cooperating lanes that split the Geff trapezoid's
+  // nodes (lgar_device.hpp geff_nodes_cooperative) -- as many as keep the job within one round of the 8-slot kernel's wave
+  // slots.  Results are bit for bit those of one lane per column.
+  a.coop = cooperating_lanes<R>(dims, wave_slots(Occupancy<R, LGAR_CAP_SMALL>::waves));
+  const bool tiny = grid <= 1024u && dims->search_mode != 2 && a.coop == 1;  // search_mode 2: chain forced (tests)
   int caps[3], nc = 0;
-  if (!tiny && need <= LGAR_CAP_SMALL && slots > LGAR_CAP_SMALL) caps[nc++] = LGAR_CAP_SMALL;
-  if (!tiny && need <= LGAR_CAP_MID && slots > LGAR_CAP_MID) caps[nc++] = LGAR_CAP_MID;
+  int first_cap = LGAR_CAP_SMALL;
+  if (a.coop > 1 && getenv("LGAR_COOP_FIRST_CAP")) first_cap = atoi(getenv("LGAR_COOP_FIRST_CAP"));  // EXPERIMENT
+  if (!tiny && need <= LGAR_CAP_SMALL && slots > LGAR_CAP_SMALL && first_cap <= LGAR_CAP_SMALL) caps[nc++] = LGAR_CAP_SMALL;
+  if (!tiny && need <= LGAR_CAP_MID && slots > LGAR_CAP_MID && first_cap <= LGAR_CAP_MID) caps[nc++] = LGAR_CAP_MID;
   caps[nc++] = LGAR_FMAX;
   for (int i = 0; i < nc; i++) {
     a.chain_first = (i == 0);
@@ -162,10 +216,11 @@ static int forward_typed(const LgarDims *dims, const LgarParams *params, LgarSta
     unsigned *tk = tickets ? tickets + i : nullptr;
     a.pending_in = (tickets && i > 0) ? tickets + 4 + (i - 1) : nullptr;   // tickets[4..5]: columns handed over by kernel 0, 1
     a.pending_out = (tickets && i < nc - 1) ? tickets + 4 + i : nullptr;
+    const bool mixed = dims->geff_mode == 1;
     switch (caps[i]) {
-      case LGAR_CAP_SMALL: launch_forward_kernel<R, NL, LGAR_CAP_SMALL, 1>(a, grid, tk, st); break;
-      case LGAR_CAP_MID: launch_forward_kernel<R, NL, LGAR_CAP_MID, 1>(a, grid, tk, st); break;
-      default: launch_forward_kernel<R, NL, LGAR_FMAX, 1>(a, grid, tk, st); break;
+      case LGAR_CAP_SMALL: launch_fast_kernel<R, NL, LGAR_CAP_SMALL>(a, grid, tk, st, mixed); break;
+      case LGAR_CAP_MID: launch_fast_kernel<R, NL, LGAR_CAP_MID>(a, grid, tk, st, mixed); break;
+      default: launch_fast_kernel<R, NL, LGAR_FMAX>(a, grid, tk, st, mixed); break;
     }
     const int rc = launch_status();
     if (rc) return rc;

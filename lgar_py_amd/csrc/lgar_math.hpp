@@ -12,7 +12,7 @@
 // Both are good to ~2.5e-16 (relative; log2 relative to max(1, |log2 x|), and relative to its own value near x = 1),
 // i.e. pow is good to ~max(1, |y log2 x|) * 7e-16 relative, nine orders of magnitude inside the 1e-6 parity bar.
 // The polynomial coefficients were fitted with mpmath.chebyfit at 60 digits (tests/test_device_math.py re-derives the
-// error bounds); -DLGAR_F64_LIBM restores ocml.  search_mode 0 (verification) uses the library pow instead (pwx).
+// error bounds).  search_mode 0 (verification) uses the library pow instead (pwx).
 #pragma once
 #ifndef LGAR_DEVSIM
 #include <hip/hip_runtime.h>

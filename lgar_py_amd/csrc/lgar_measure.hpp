@@ -1,0 +1,117 @@
+// lgar_measure.hpp -- MEASUREMENT BUILDS ONLY (lgar_py_amd.build.build_variant passes -DLGAR_MEASURE; tools/ablate.py).
+//
+// Definitions of the measurement points the device code marks (lgar_device.hpp: LGAR_MEASURE_POINT, LGAR_ABLATABLE,
+// LGAR_COUNT_GEFF_CALL).  The product library never includes this file: there the points are empty.
+//   -DLGAR_DUP_<X>     routine X runs twice on opaque copies of its inputs, results unchanged: the time difference to the
+//                      plain build is X's cost with the column dynamics (and so all other work) untouched
+//   -DLGAR_ABL_NO<X>   statement X is left out (what the register allocator / the schedule does without it)
+//   -DLGAR_COUNT_*     what the Geff-call counter counts (one call site, only sparse evaluations, lanes instead of waves)
+// The macros expand inside member functions of lgar::Column and use its members and the locals passed to them.
+#pragma once
+
+// (included from inside namespace lgar)
+__device__ __forceinline__ float opaque(float x) { asm volatile("" : "+v"(x)); return x; }
+__device__ __forceinline__ double opaque(double x) { asm volatile("" : "+v"(x)); return x; }
+
+#define LGAR_MEASURE_POINT(NAME, ...) LGAR_POINT_##NAME(__VA_ARGS__)
+#define LGAR_ABLATABLE(NAME, ...) LGAR_STMT_##NAME(__VA_ARGS__)
+
+// ---- statements a build can leave out
+#ifdef LGAR_ABL_NOINSERT
+#define LGAR_STMT_INSERT(...)
+#else
+#define LGAR_STMT_INSERT(...) __VA_ARGS__
+#endif
+#ifdef LGAR_ABL_NOMOVE
+#define LGAR_STMT_MOVE(...)
+#else
+#define LGAR_STMT_MOVE(...) __VA_ARGS__
+#endif
+#ifdef LGAR_ABL_NODZDT
+#define LGAR_STMT_DZDT(...)
+#else
+#define LGAR_STMT_DZDT(...) __VA_ARGS__
+#endif
+
+// ---- capillary_drive
+#ifdef LGAR_ABL_NOGEFF  // the kernel without the trapezoid
+#define LGAR_POINT_NOGEFF(lk, theta1, theta2) return theta1 * theta2 + lk.alpha;
+#else
+#define LGAR_POINT_NOGEFF(lk, theta1, theta2)
+#endif
+#ifdef LGAR_COUNT_SITE  // count one call site only (1 dzdt, 2 dry depth, 3 insert)
+#define LGAR_COUNT_IF_SITE(site) if (site == LGAR_COUNT_SITE)
+#else
+#define LGAR_COUNT_IF_SITE(site)
+#endif
+#ifdef LGAR_COUNT_MAXLANES  // ... and only the evaluations with at most this many lanes taking part
+#define LGAR_COUNT_IF_SPARSE if (__builtin_popcountll(any_lane(true)) <= LGAR_COUNT_MAXLANES)
+#else
+#define LGAR_COUNT_IF_SPARSE
+#endif
+#ifdef LGAR_COUNT_LANES  // every evaluating lane counts
+#define LGAR_COUNT_WHO count_geff
+#else
+#define LGAR_COUNT_WHO (count_geff && first_active_lane())
+#endif
+#define LGAR_COUNT_GEFF_CALL(site) \
+  LGAR_COUNT_IF_SITE(site) LGAR_COUNT_IF_SPARSE { if (LGAR_COUNT_WHO) status += (1 << LGAR_ST_STEP_SHIFT); }
+#ifdef LGAR_DUP_GEFF
+#define LGAR_POINT_DUP_GEFF(lk, theta1, theta2)                                                    \
+  if constexpr (sizeof(S) == sizeof(R)) {                                                          \
+    const S extra = geff(lk, opaque(theta1), opaque(theta2), G->nint);                             \
+    if (val(extra) == R(12345.678)) return extra; /* practically never true: keeps the duplicate alive */ \
+  }
+#else
+#define LGAR_POINT_DUP_GEFF(lk, theta1, theta2)
+#endif
+
+// ---- theta_mass_balance
+#ifdef LGAR_ABL_NOSEARCH
+#define LGAR_POINT_NOSEARCH(lk, psi, new_mass) return theta_from_h<S, POL>(lk, psi + new_mass);
+#else
+#define LGAR_POINT_NOSEARCH(lk, psi, new_mass)
+#endif
+#ifdef LGAR_DUP_SEARCH
+#define LGAR_POINT_DUP_SEARCH(K, lk, psi, new_mass, prior_mass, dth, dthick, dth_k, dthick_k)      \
+  if constexpr (sizeof(S) == sizeof(R)) {                                                          \
+    const S extra = theta_mass_balance<K>(lk, opaque(psi), opaque(new_mass), opaque(prior_mass), dth, dthick, dth_k, dthick_k); \
+    if (val(extra) == R(-1.0)) status |= LGAR_ST_STRUCT; /* never true */                          \
+  }
+#else
+#define LGAR_POINT_DUP_SEARCH(...)
+#endif
+
+// ---- move_wetting_front / forward
+#ifdef LGAR_DUP_EVENT
+#define LGAR_POINT_DUP_EVENT()                                                                     \
+  if (front_event_pending() && val(F.Z(0)) == R(-12345.0)) status |= LGAR_ST_STRUCT; /* never true */ \
+  asm volatile("" ::: "memory");
+#else
+#define LGAR_POINT_DUP_EVENT()
+#endif
+#ifdef LGAR_DUP_PSI
+#define LGAR_POINT_DUP_PSI() asm volatile("" ::: "memory"); update_psi();
+#else
+#define LGAR_POINT_DUP_PSI()
+#endif
+#ifdef LGAR_DUP_FDD
+#define LGAR_POINT_DUP_FDD()                                                                       \
+  if (free_drainage_front() == 12345) status |= LGAR_ST_STRUCT; /* never true */                   \
+  asm volatile("" ::: "memory");
+#else
+#define LGAR_POINT_DUP_FDD()
+#endif
+#ifdef LGAR_DUP_DZDT  // idempotent: a second pass recomputes the same dz/dt (Geff included)
+#define LGAR_POINT_DUP_DZDT(h_p) asm volatile("" ::: "memory"); calc_dzdt(h_p);
+#else
+#define LGAR_POINT_DUP_DZDT(h_p)
+#endif
+#ifdef LGAR_DUP_MB
+#define LGAR_POINT_DUP_MB(volume)                                                                  \
+  volume = mass_balance();                                                                         \
+  asm volatile("" ::: "memory");                                                                   \
+  if (val(volume) == R(-1.0)) status |= LGAR_ST_STRUCT; /* never true */
+#else
+#define LGAR_POINT_DUP_MB(volume)
+#endif

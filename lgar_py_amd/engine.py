@@ -31,6 +31,10 @@ class LgarEngine:
     (8 -> 16 -> 32 slots, include/lgar.h) forced even for small jobs (tests).
     front_slots: rows of the per-front state arrays = the most fronts a column can hold (<= 32; the reference's lists are
     unbounded, Layer.py:1336-1416).
+    geff_precision: "native" (default) = the Geff trapezoid (lgar/green_ampt.py:45-84) in `dtype`; "f32" (fp64 fast modes
+    only) = mixed precision: fp64 column state, branches, mass bookkeeping, trapezoid heads and end nodes; the 119 interior
+    nodes with the fp32 hardware transcendentals, summed in fp64 (LgarDims.geff_mode = 1; DESIGN.md section 4 states the
+    tolerance this reaches against the reference).
     bottom_mode: 0 (default) = like the reference, a front reaching the domain bottom faults the column; 1 = it leaves
     the column as percolation (LGAR-C intent; parity unpinned, the reference crashes there).
     """
@@ -38,7 +42,8 @@ class LgarEngine:
     def __init__(self, alpha, n, ksat, theta_e, theta_r, thickness, *, n_columns=None, dt_h=1.0, num_subcycles=1,
                  initial_psi=2000.0, ponded_depth_max=0.0, wilting_point_psi=15495.0, frozen_factor=1.0, nint=120,
                  giuh_ordinates=(0.06, 0.51, 0.28, 0.12, 0.03), dtype=torch.float64, device="cuda:0",
-                 iter_cap=0, search_mode=1, bottom_mode=0, use_closed_form_G=False, front_slots=None, with_state=True):
+                 iter_cap=0, search_mode=1, bottom_mode=0, use_closed_form_G=False, front_slots=None, with_state=True,
+                 geff_precision="native", forward_lanes=0):
         self.device = torch.device(device)
         _require_gpu(self.device)
         self.lib = _capi.load()
@@ -85,6 +90,15 @@ class LgarEngine:
         d.iter_cap = int(iter_cap)
         d.bottom_mode = int(bottom_mode)
         d.use_closed_form_G = int(bool(use_closed_form_G))
+        if geff_precision not in ("native", "f32"):
+            raise LgarError("geff_precision must be 'native' or 'f32'")
+        if geff_precision == "f32" and (dtype != torch.float64 or int(search_mode) == 0):
+            raise LgarError("geff_precision='f32' is the mixed mode of the fp64 fast searches (dtype float64, search_mode 1 or 2)")
+        d.geff_mode = 1 if geff_precision == "f32" else 0
+        self.geff_precision = geff_precision
+        # lanes per column in lgar_forward: 0 = the library gives small fp64 jobs 2..64 cooperating lanes per column (same
+        # results bit for bit), 1 = never, 2..64 = exactly that many (tests)
+        d.forward_lanes = int(forward_lanes)
         FMAX = int(front_slots) if front_slots else _capi.FMAX
         if not L + 1 <= FMAX <= _capi.FMAX:
             raise LgarError("front_slots must be in %d..%d" % (L + 1, _capi.FMAX))
@@ -296,7 +310,7 @@ def leaf_batch(op, x, y=None, z=0.0, *, alpha, n, ksat, theta_e, theta_r, nint=1
     _require_gpu(dev)
     lib = _capi.load()
     ops = {"theta_from_h": 0, "se_from_h": 1, "k_from_se": 2, "h_from_se": 3, "geff": 4, "aet": 5, "geff_literal": 6,
-           "log2": 7, "exp2": 8, "pow": 9}
+           "log2": 7, "exp2": 8, "pow": 9, "geff_mixed": 10}
     prep = lambda t: None if t is None else torch.as_tensor(t, dtype=torch.float64).to(dev, dtype).contiguous()
     x, y, alpha, n, ksat, theta_e, theta_r = map(prep, (x, y, alpha, n, ksat, theta_e, theta_r))
     out = torch.empty_like(x)

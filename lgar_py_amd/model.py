@@ -118,11 +118,13 @@ class dpLGAR(nn.Module):
                                  wilting_point_psi=float(cfg.data.wilting_point_psi), frozen_factor=ff,
                                  nint=int(cfg.constants.nint), giuh_ordinates=tuple(cfg.data.giuh_ordinates),
                                  use_closed_form_G=bool(cfg.data.use_closed_form_G),
+                                 geff_precision=str(cfg.get("geff_precision", "native") or "native"),
                                  dtype=self.dtype, device=self.device)
         self.c = self._soil_metrics(te, tr)
         from .autograd import StepTape
         self.tape = StepTape(self)
         self._latest = None  # ponded_water / ending_volume as of the last forward() (rows 8, 9 of its call_sums)
+        self.steps_advanced = 0  # forcing rows integrated since this reset (the tape checks its record against it)
         self.num_wetting_fronts = self.calc_num_wetting_fronts()
         # Small models keep the accumulator attributes on the HOST, where the reference keeps them: the agent's loop touches
         # ~20 of them per forcing row (MassBalance.change_mass), and each touch of a GPU tensor is a kernel launch.
@@ -177,6 +179,8 @@ class dpLGAR(nn.Module):
         grad_mode = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         want = ("runoff", "percolation") if (series_mode or grad_mode) else ()
         out = self.engine.forward(x[:, :, 0], x[:, :, 1], series=want, check=False, call_sums=True)
+        steps_before = self.steps_advanced
+        self.steps_advanced += int(x.shape[0])
         # the 8 accumulators summed over this call's steps (+ latest ponded_water / ending_volume), [8+2, N]
         sums = out["call_sums"].to(self.attr_device, torch.float64)
         self._latest = sums[8:10]
@@ -189,7 +193,7 @@ class dpLGAR(nn.Module):
             # graph-connected outputs (models/dpLGAR.py:299): this block's per-step runoff / percolation become the
             # outputs of an autograd node whose inputs are the parameters (autograd.StepTape)
             r_series, p_series = self.tape.record(x, r_series.to(self.attr_device, torch.float64),
-                                                  p_series.to(self.attr_device, torch.float64))
+                                                  p_series.to(self.attr_device, torch.float64), steps_before)
             self.runoff = self.runoff + self._shape(r_series.sum(0))
             self.percolation = self.percolation + self._shape(p_series.sum(0))
         self.previous_precip = self._shape((x[-1, :, 0] * float(self.cfg.models.subcycle_length_h)).to(self.attr_device))

@@ -3,7 +3,7 @@ reference tree (the GPU box has no /root/reference).
 
 The synth_1 forcing shape is restated from /root/reference/data/forcing_data_synth_1.txt
 (144 rows @ 5 min; P = 20 mm/h for rows 6-10 and 59-128, else 0; PET = 0) and checked against the
-golden fixture in tests/test_workloads.py.  Soil parameters are the Phillipsburg P-1..3 rows
+golden fixture in tests/test_capi_host.py (test_workloads_match_fixtures).  Soil parameters are the Phillipsburg P-1..3 rows
 (/root/reference/dpLGAR/data/utils.py:123-125,146-148,170-172; data/vG_default_params.dat:14-16).
 """
 import numpy as np

@@ -26,7 +26,7 @@ class LgarDims(C.Structure):
                 ("dt_h", C.c_double), ("initial_psi", C.c_double), ("ponded_depth_max", C.c_double),
                 ("wilting_point_psi", C.c_double), ("frozen_factor", C.c_double), ("giuh", C.c_double * GMAX),
                 ("iter_cap", C.c_int64), ("forcing_columns", C.c_int32), ("forcing_group", C.c_int32),
-                ("tangent_share", C.c_int32), ("reserved3", C.c_int32)]
+                ("tangent_share", C.c_int32), ("geff_mode", C.c_int32), ("forward_lanes", C.c_int32), ("reserved4", C.c_int32)]
 
 
 class LgarParams(C.Structure):
@@ -85,7 +85,7 @@ class SimEngine:
     def __init__(self, alpha, n, ksat, theta_e, theta_r, thickness, *, n_columns=None, dt_h=1.0, num_subcycles=1,
                  initial_psi=2000.0, ponded_depth_max=0.0, wilting_point_psi=15495.0, frozen_factor=1.0, nint=120,
                  giuh_ordinates=(0.06, 0.51, 0.28, 0.12, 0.03), dtype=np.float64, iter_cap=0, search_mode=1, bottom_mode=0,
-                 use_closed_form_G=False, front_slots=None):
+                 use_closed_form_G=False, front_slots=None, geff_mode=0):
         self.dtype = np.dtype(dtype)
         self._dt = 1 if self.dtype == np.float64 else 0
 
@@ -108,6 +108,7 @@ class SimEngine:
         for i, g in enumerate(giuh_ordinates):
             d.giuh[i] = float(g)
         d.iter_cap, d.bottom_mode, d.use_closed_form_G = int(iter_cap), int(bottom_mode), int(bool(use_closed_form_G))
+        d.geff_mode = int(geff_mode)
         F = int(front_slots) if front_slots else FMAX
         d.front_slots = F
         z = lambda *s, dt=self.dtype: np.zeros(s, dtype=dt)

@@ -75,6 +75,14 @@ int forward_typed(const LgarDims *d, const LgarParams *p, LgarState *s, const Lg
   caps[nc++] = LGAR_FMAX;
   for (int i = 0; i < nc; i++) {
     a.chain_first = (i == 0); a.chain_last = (i == nc - 1);
+    if constexpr (sizeof(R) == 8) {
+      if (d->geff_mode == 1) {  // mixed-precision trapezoid (MODE 3)
+        if (caps[i] == LGAR_CAP_SMALL) run_forward<R, NL, LGAR_CAP_SMALL, 3>(a);
+        else if (caps[i] == LGAR_CAP_MID) run_forward<R, NL, LGAR_CAP_MID, 3>(a);
+        else run_forward<R, NL, LGAR_FMAX, 3>(a);
+        continue;
+      }
+    }
     if (caps[i] == LGAR_CAP_SMALL) run_forward<R, NL, LGAR_CAP_SMALL, 1>(a);
     else if (caps[i] == LGAR_CAP_MID) run_forward<R, NL, LGAR_CAP_MID, 1>(a);
     else run_forward<R, NL, LGAR_FMAX, 1>(a);
@@ -128,6 +136,26 @@ void devsim_math(int op, int n, const double *x, const double *y, double *out) {
       case 2: out[i] = fast_pow(x[i], y[i]); break;
       case 3: out[i] = fast_exp2_core<false>(x[i]); break;
       case 4: out[i] = fast_log2_core(x[i]); break;
+    }
+  }
+}
+
+// element-wise Geff variants on host doubles: 0 fused fp64 (fast modes), 1 mixed precision (geff_mode 1), 2 the reference's
+// literal trapezoid with the library pow, 3 the packed fp32 loop (inputs rounded to float)
+void devsim_geff(int variant, int n, const double *theta1, const double *theta2, const double *alpha, const double *nn,
+                 const double *ksat, const double *te, const double *tr, int nint, double *out) {
+  for (int i = 0; i < n; i++) {
+    LayerK<double> l;
+    l.alpha = alpha[i]; l.n = nn[i]; l.m = 1.0 - 1.0 / l.n; l.inv_m = 1.0 / l.m; l.inv_n = 1.0 / l.n;
+    l.ksat = ksat[i]; l.te = te[i]; l.tr = tr[i];
+    if (variant == 0) out[i] = geff_fused<double>(l, theta1[i], theta2[i], nint);
+    else if (variant == 1) out[i] = geff_mixed(l, theta1[i], theta2[i], nint);
+    else if (variant == 2) out[i] = geff_literal<double, 1>(l, theta1[i], theta2[i], nint);
+    else {
+      LayerK<float> f;
+      f.alpha = (float)l.alpha; f.n = (float)l.n; f.m = 1.0f - 1.0f / f.n; f.inv_m = 1.0f / f.m; f.inv_n = 1.0f / f.n;
+      f.ksat = (float)l.ksat; f.te = (float)l.te; f.tr = (float)l.tr;
+      out[i] = (double)geff<float>(f, (float)theta1[i], (float)theta2[i], nint);
     }
   }
 }

@@ -77,6 +77,104 @@ def test_device_code_literal_mode_vs_reference_golden(name):
     assert int(eng.n_fronts[0]) == int(g["nfronts"][T - 1]) and int(eng.status[0]) == 0
 
 
+# Mixed-precision Geff (LgarDims.geff_mode = 1: fp64 state, fp32 hardware transcendentals in the trapezoid's interior nodes).
+# What it reaches against the reference: a Geff value carries a RANDOM relative error of ~1e-8 (<= 2e-7),
+# which the column dynamics pass on to the fluxes 1:1 except at front events, where one step's infiltration can move by up to
+# ~50x that -- and a runoff that is the small difference of rainfall and infiltration moves by the same ABSOLUTE amount.  So
+# the bars are: front tables 1e-6; every per-step output within 5e-6 of the water moving through the column in that step
+# (5e-6 of max(|value|, rainfall + ponding of the step, 1e-3 cm)); run totals 2e-6 of max(|total|, total rainfall); and, as a backstop, 1e-3 relative on
+# every single per-step value (observed: 1.7e-4 on a 1.1e-3 cm runoff whose absolute error is 2e-7 cm).
+MIXED_FLUX, MIXED_TOTAL, MIXED_STEP_BACKSTOP = 5e-6, 2e-6, 1e-3
+
+
+def mixed_mode_check(acc, ref, T):
+    """acc, ref: [T, NACC] per-step outputs of the mixed mode and of the reference"""
+    scale = np.maximum(np.maximum(ref[:, 0:1] + ref[:, 8:9], np.abs(ref)), 1e-3)
+    assert (np.abs(acc - ref) / scale).max() <= MIXED_FLUX
+    assert _rel(acc, ref).max() <= MIXED_STEP_BACKSTOP
+    tot, rtot = acc[:, :8].sum(0), ref[:, :8].sum(0)
+    assert (np.abs(tot - rtot) / np.maximum(np.maximum(np.abs(rtot), rtot[0]), 1e-2)).max() <= MIXED_TOTAL
+
+
+@pytest.mark.parametrize("name", TRAJ)
+def test_device_code_mixed_precision_geff_vs_reference_golden(name):
+    import devsim
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    crash = int(g["crash_step"])
+    T = crash if crash >= 0 else g["forcing"].shape[0]
+    eng = _engine(g, 2, search_mode=2, geff_mode=1)
+    f = g["forcing"][:T]
+    out = eng.forward(np.repeat(f[:, 0:1], 2, 1), np.repeat(f[:, 1:2], 2, 1), series=devsim.ACC_NAMES)
+    acc = np.stack([out[nm][:, 0] for nm in devsim.ACC_NAMES], 1)
+    mixed_mode_check(acc, g["acc"][:T], T)
+    assert all((out[nm][:, 0] == out[nm][:, 1]).all() for nm in devsim.ACC_NAMES)
+    assert (eng.status == 0).all()
+    nf = int(g["nfronts"][T - 1])
+    fr = eng.fronts()
+    assert (fr["n_fronts"] == nf).all()
+    assert _rel(fr["depth"][:nf, 0], g["fronts"][T - 1, :nf, 0]).max() <= 1e-6
+    assert _rel(fr["theta"][:nf, 0], g["fronts"][T - 1, :nf, 1]).max() <= 1e-6
+    assert (fr["layer"][:nf, 0] == g["front_layer"][T - 1, :nf]).all()
+    assert (fr["to_bottom"][:nf, 0] == g["front_bottom"][T - 1, :nf]).all()
+    if crash >= 0:  # the reference raised at this step: the column must fault here too
+        f1 = g["forcing"][T:T + 1]
+        eng.forward(np.repeat(f1[:, 0:1], 2, 1), np.repeat(f1[:, 1:2], 2, 1), series=())
+        assert (eng.status != 0).all()
+
+
+def test_mixed_precision_geff_leaf_accuracy():
+    """The mixed trapezoid against the reference's literal one (library pow) over the ranges the three call sites see: no
+    systematic error, <= 3e-7 relative for every input (observed on the CPU: median 8e-9, 99th percentile 7e-8, max 1.6e-7;
+    the plain fp32 loop: median 1e-6, 99th percentile 6e-4)."""
+    import ctypes as C
+    import devsim
+    L = devsim.lib(3)
+    dp = np.ctypeslib.ndpointer(dtype=np.float64)
+    L.devsim_geff.argtypes = [C.c_int, C.c_int, dp, dp, dp, dp, dp, dp, dp, C.c_int, dp]
+    rng = np.random.default_rng(0)
+    n = 4000
+    alpha, nn = rng.uniform(0.003, 0.009, n), rng.uniform(1.25, 1.75, n)
+    ks, te, tr = np.full(n, 0.3), np.full(n, 0.46), np.full(n, 0.07)
+
+    def run(v, t1, t2):
+        o = np.zeros(n)
+        L.devsim_geff(v, n, np.ascontiguousarray(t1), np.ascontiguousarray(t2), alpha, nn, ks, te, tr, 120, o)
+        return o
+
+    theta = lambda h: tr + (te - tr) * (1 + (alpha * h) ** nn) ** -(1 - 1 / nn)
+    h1 = 10 ** rng.uniform(0.5, 3.3, n)
+    for t1, t2 in ((theta(h1), te.copy()), (theta(h1), theta(h1 * 10 ** rng.uniform(-2, -0.05, n))),
+                   (theta(h1), theta(h1 * rng.uniform(0.7, 0.98, n)))):
+        ref, mix = run(2, t1, t2), run(1, t1, t2)
+        e = (mix - ref) / ref
+        assert np.abs(e).max() <= 3e-7 and np.median(np.abs(e)) <= 3e-8 and abs(e.mean()) <= 1e-8
+        assert np.abs(run(0, t1, t2) - ref).max() <= 1e-11 * np.abs(ref).max()  # the fused fp64 trapezoid, for scale
+
+
+def test_mixed_precision_flags_the_columns_the_oracle_flags():
+    """Fault parity of the mixed mode on the +-10 % ensemble (the reference raises on ~13 % of it): same columns flagged,
+    the others within the mixed-mode bars."""
+    import devsim
+    from lgar_py_amd import workloads as W
+    from oracle import lgar_oracle as O
+    N = 192
+    P = W.perturbed_columns(N, seed=7)
+    sc = W.forcing_scale(N, seed=8)
+    f = W.synth1_forcing()
+    pr = f[:, 0:1] * sc[None, :]
+    pe = np.zeros_like(pr)
+    ro, pc, acc, st = O.run_columns(P["alpha"], P["n"], P["ksat"], P["theta_e"], P["theta_r"], P["thickness"], pr, pe,
+                                    pdm=0.0, dt_h=300.0 / 3600.0)
+    eng = devsim.SimEngine(P["alpha"], P["n"], P["ksat"], P["theta_e"], P["theta_r"], P["thickness"], dt_h=300.0 / 3600.0,
+                           ponded_depth_max=0.0, search_mode=1, geff_mode=1)
+    out = eng.forward(pr, pe, series=("runoff",))
+    assert ((st != 0) == (eng.status != 0)).all()
+    ok = st == 0
+    assert np.abs(out["runoff"][:, ok] - ro[:, ok]).max() <= MIXED_FLUX * max(1.0, np.abs(ro).max())
+    scale = np.maximum(np.maximum(np.abs(acc[:8]), acc[0:1]), 1e-2)  # a column's totals against its water input
+    assert (np.abs(eng.totals[:8] - acc[:8]) / scale)[:, ok].max() <= MIXED_TOTAL
+
+
 def test_capacity_chain_hands_columns_over_and_resumes():
     """Columns with few fronts finish in the 8-slot kernel, the others move to 16 and 32 slots at different steps of the
     same call; results equal the single-kernel run bitwise, chunked calls included, and the per-call sums add up."""

@@ -25,8 +25,7 @@ VARIANTS = {
     "nogeff_nodzdt": ["-DLGAR_ABL_NOGEFF", "-DLGAR_ABL_NODZDT"],
     "nogeff_nomove": ["-DLGAR_ABL_NOGEFF", "-DLGAR_ABL_NOMOVE"],
     "nogeff_noinsert": ["-DLGAR_ABL_NOGEFF", "-DLGAR_ABL_NOINSERT"],
-    "nogeff_noepi": ["-DLGAR_ABL_NOGEFF", "-DLGAR_ABL_NOEPILOGUE"],
-    "skeleton": ["-DLGAR_ABL_NOGEFF", "-DLGAR_ABL_NODZDT", "-DLGAR_ABL_NOMOVE", "-DLGAR_ABL_NOINSERT", "-DLGAR_ABL_NOEPILOGUE"],
+    "skeleton": ["-DLGAR_ABL_NOGEFF", "-DLGAR_ABL_NODZDT", "-DLGAR_ABL_NOMOVE", "-DLGAR_ABL_NOINSERT"],
     "contract": ["-ffp-contract=fast"],
     "count_lanes": ["-DLGAR_COUNT_LANES"],  # geff_calls then counts LANE-level evaluations (base: wave-level)
     "site1_waves": ["-DLGAR_COUNT_SITE=1"], "site1_lanes": ["-DLGAR_COUNT_SITE=1", "-DLGAR_COUNT_LANES"],  # calc_dzdt
@@ -34,7 +33,6 @@ VARIANTS = {
     "site1_le8": ["-DLGAR_COUNT_SITE=1", "-DLGAR_COUNT_MAXLANES=8"], "site1_le48": ["-DLGAR_COUNT_SITE=1", "-DLGAR_COUNT_MAXLANES=48"],
     "site2_waves": ["-DLGAR_COUNT_SITE=2"], "site2_lanes": ["-DLGAR_COUNT_SITE=2", "-DLGAR_COUNT_LANES"],  # dry depth
     "site3_waves": ["-DLGAR_COUNT_SITE=3"], "site3_lanes": ["-DLGAR_COUNT_SITE=3", "-DLGAR_COUNT_LANES"],  # insert_water
-    "tan_nopair": ["-DLGAR_NO_FUSED_PAIR"],  # dual-number Geff one node per iteration (run tools/bench_autograd.py on it)
     "occ3": ["-DLGAR_OCC_F32_SMALL=3"],
     "occ2": ["-DLGAR_OCC_F32_SMALL=2"],
     "occ1_f64": ["-DLGAR_OCC_F64_SMALL=1"],
