@@ -110,10 +110,13 @@ typedef struct {
                                 stay fp64, the two heads and the two end nodes of the trapezoid stay fp64, its 119 interior
                                 nodes use the fp32 hardware transcendentals and are summed in fp64 */
   int32_t forward_lanes;     /* lgar_forward, LGAR_F64 fast modes with the trapezoid (ignored elsewhere).  0: the library decides --
-                                jobs too small to fill the chip get 2..64 cooperating lanes per column, which split the nodes of
+                                jobs under one wave per SIMD get 8..64 cooperating lanes per column, which split the nodes of
                                 the Geff trapezoid between them (results bit for bit those of one lane per column); 1: one lane
                                 per column whatever the job size; 2, 4, .. 64: that many */
-  int32_t reserved4;
+  int32_t tangent_plain_tail; /* lgar_forward_tangent with tangent_share = 8 only.  The LAST this-many columns stand alone (no
+                                sharing): column c of that tail reads forcing / weight column (c - first tail column) %
+                                forcing_columns.  n_columns - tangent_plain_tail must be a multiple of 64.  (A backward pass over
+                                3 x L = 9 parameters rides as 8 shared directions + 1 in the tail of ONE launch.) */
 } LgarDims;
 
 /* Per-column soil parameters, each [n_layers][n_columns].  Replaces dpLGAR.alpha/.n/.ksat
@@ -191,10 +194,14 @@ int32_t lgar_forward(const LgarDims *dims, const LgarParams *params, LgarState *
  * (set_internal_states) over n_steps and accumulates, per column,
  *     grad_out[column] = sum_t  w_runoff[t][column] * d runoff_t + w_perc[t][column] * d percolation_t
  * (w_* may be NULL).  Line-search offsets are constants w.r.t. the parameters, as in the reference
- * (Layer.py:277-288,683-696).  tangent_runoff ([n_steps][n_columns]) may be NULL. */
+ * (Layer.py:277-288,683-696).  tangent_runoff ([n_steps][n_columns]) may be NULL.
+ * tickets: NULL or device uint32[LGAR_NTICKETS] (zeroed by the library on the stream): with it the kernels run as one
+ * resident wave per wave slot of the chip, each pulling 64-column blocks (the stand-alone tail first: its blocks take
+ * longest) until none is left. */
 int32_t lgar_forward_tangent(const LgarDims *dims, const LgarParams *params, const LgarParams *direction,
                              const LgarForcing *forcing, const void *w_runoff, const void *w_perc,
-                             void *grad_out, void *tangent_runoff, int32_t *status, int32_t dtype, void *stream);
+                             void *grad_out, void *tangent_runoff, int32_t *status, int32_t dtype, void *stream,
+                             uint32_t *tickets);
 
 /* Leaf kernels (known-answer tests on the GPU), element-wise over n items:
  * op 0 theta_from_h(x), 1 se_from_h(x), 2 k_from_se(x), 3 h_from_se(x)      (physics/utils.py:35-174)

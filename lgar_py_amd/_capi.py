@@ -32,7 +32,7 @@ class LgarDims(C.Structure):
                 ("dt_h", C.c_double), ("initial_psi", C.c_double), ("ponded_depth_max", C.c_double),
                 ("wilting_point_psi", C.c_double), ("frozen_factor", C.c_double), ("giuh", C.c_double * GMAX),
                 ("iter_cap", C.c_int64), ("forcing_columns", C.c_int32), ("forcing_group", C.c_int32),
-                ("tangent_share", C.c_int32), ("geff_mode", C.c_int32), ("forward_lanes", C.c_int32), ("reserved4", C.c_int32)]
+                ("tangent_share", C.c_int32), ("geff_mode", C.c_int32), ("forward_lanes", C.c_int32), ("tangent_plain_tail", C.c_int32)]
 
 
 class LgarParams(C.Structure):
@@ -91,7 +91,7 @@ def load():
     if hasattr(lib, "lgar_forward_tangent") or not os.environ.get("LGAR_LIB"):  # measurement variants omit it
         lib.lgar_forward_tangent.restype = i32
         lib.lgar_forward_tangent.argtypes = [p(LgarDims), p(LgarParams), p(LgarParams), p(LgarForcing), vp, vp, vp, vp, vp,
-                                             i32, vp]
+                                             i32, vp, vp]
     lib.lgar_leaf_batch.restype = i32
     lib.lgar_leaf_batch.argtypes = [i32, i32, vp, vp, dbl, vp, vp, vp, vp, vp, i32, dbl, vp, i32, vp]
     lib.lgar_valu_probe_insts.restype = i32

@@ -41,17 +41,33 @@ def parameter_vjp(eng, precip, pet, w_runoff, w_perc, wanted, check=True):
     group = max(1, min(D, BATCH_DIRECTIONS_MAX_COLUMNS // max(N, 1)))
     d = eng.dims
     # fp64 fast modes: groups of exactly 8 directions let the 8 lanes of a column share the transcendentals of the Geff
-    # trapezoid (LgarDims.tangent_share); the remaining directions go as before
-    # (only when the shared launch fills the chip: a small job is bound by the latency of ONE wave, and two launches in a row
-    # -- shared group, then the left-over directions -- would double it)
+    # trapezoid (LgarDims.tangent_share); directions left over after the last full group ride in the SAME launch as a
+    # stand-alone tail (LgarDims.tangent_plain_tail: 3 x L = 9 parameters -> 8 shared + 1 tail, one launch, no second tail of
+    # half-empty rounds)
+    # (only when the shared launch fills the chip: a small job is bound by the latency of ONE wave)
     share8 = (eng.dtype == torch.float64 and d.search_mode != 0 and not d.use_closed_form_G and group >= 8
               and N >= SHARE_MIN_COLUMNS)
+    tail_ok = share8 and N % 8 == 0 and (D % 8) * N + 8 * N <= BATCH_DIRECTIONS_MAX_COLUMNS
     if share8:
         group = 8
-    for g0 in range(0, D, group):
-        part = wanted[g0:g0 + group]
+    chunks = [wanted[g0:g0 + group] for g0 in range(0, D, group)]
+    tails = []
+    if tail_ok and len(chunks) >= 2 and len(chunks[-1]) < 8:
+        tails = chunks.pop()  # the left-over directions: the tail of the last shared launch
+
+    def big_engine(rep):
+        return LgarEngine(rep(eng.alpha), rep(eng.n), rep(eng.ksat), rep(eng.theta_e), rep(eng.theta_r), rep(eng.thickness),
+                          dt_h=d.dt_h, num_subcycles=d.num_subcycles, initial_psi=d.initial_psi,
+                          ponded_depth_max=d.ponded_depth_max, wilting_point_psi=d.wilting_point_psi,
+                          frozen_factor=d.frozen_factor, nint=d.nint, giuh_ordinates=tuple(d.giuh[i] for i in range(d.n_giuh)),
+                          dtype=eng.dtype, device=eng.device, iter_cap=d.iter_cap, search_mode=d.search_mode,
+                          bottom_mode=d.bottom_mode, use_closed_form_G=bool(d.use_closed_form_G), front_slots=eng.front_slots,
+                          with_state=False)
+
+    for ci, part in enumerate(chunks):
         Dg = len(part)
-        if Dg == 1:
+        tail = tails if (tails and ci == len(chunks) - 1) else []
+        if Dg == 1 and not tail:
             kind, l = part[0]
             dmat = torch.zeros(L, N, dtype=eng.dtype, device=eng.device)
             dmat[l] = 1.0
@@ -59,23 +75,24 @@ def parameter_vjp(eng, precip, pet, w_runoff, w_perc, wanted, check=True):
             status |= st
             continue
         # column n's Dg directions sit in ADJACENT lanes (column n * Dg + b): they follow the same branches, so a wavefront
-        # diverges over 64 / Dg columns instead of 64; the kernel reads forcing / weight column c // Dg (forcing_group)
-        rep = lambda t: t.repeat_interleave(Dg, dim=1)
-        big = LgarEngine(rep(eng.alpha), rep(eng.n), rep(eng.ksat), rep(eng.theta_e), rep(eng.theta_r), rep(eng.thickness),
-                         dt_h=d.dt_h, num_subcycles=d.num_subcycles, initial_psi=d.initial_psi,
-                         ponded_depth_max=d.ponded_depth_max, wilting_point_psi=d.wilting_point_psi,
-                         frozen_factor=d.frozen_factor, nint=d.nint, giuh_ordinates=tuple(d.giuh[i] for i in range(d.n_giuh)),
-                         dtype=eng.dtype, device=eng.device, iter_cap=d.iter_cap, search_mode=d.search_mode,
-                         bottom_mode=d.bottom_mode, use_closed_form_G=bool(d.use_closed_form_G), front_slots=eng.front_slots,
-                         with_state=False)
-        dirs = {k: torch.zeros(L, Dg * N, dtype=eng.dtype, device=eng.device) for k in KINDS}
+        # diverges over 64 / Dg columns instead of 64; the kernel reads forcing / weight column c // Dg (forcing_group).
+        # Tail directions follow direction-major (column Dg * N + t * N + n: direction t of column n).
+        Nt = len(tail) * N
+        rep = lambda t: torch.cat([t.repeat_interleave(Dg, dim=1), t.repeat(1, len(tail))], dim=1) if tail else t.repeat_interleave(Dg, dim=1)
+        big = big_engine(rep)
+        dirs = {k: torch.zeros(L, Dg * N + Nt, dtype=eng.dtype, device=eng.device) for k in KINDS}
         for b, (kind, l) in enumerate(part):
-            dirs[kind][l, b::Dg] = 1.0
+            dirs[kind][l, b:Dg * N:Dg] = 1.0
+        for t, (kind, l) in enumerate(tail):
+            dirs[kind][l, Dg * N + t * N:Dg * N + (t + 1) * N] = 1.0
         g, _, st = big.tangent(dirs, precip, pet, w_runoff=w_runoff, w_perc=w_perc, forcing_group=Dg,  # forcing / weights broadcast by the kernel
-                               share=8 if (share8 and Dg == 8) else 0)
+                               share=8 if (share8 and Dg == 8) else 0, plain_tail=Nt)
         for b, key in enumerate(part):
-            out[key] = g[b::Dg].contiguous()
-            status |= st[b::Dg]
+            out[key] = g[b:Dg * N:Dg].contiguous()
+            status |= st[b:Dg * N:Dg]
+        for t, key in enumerate(tail):
+            out[key] = g[Dg * N + t * N:Dg * N + (t + 1) * N].contiguous()
+            status |= st[Dg * N + t * N:Dg * N + (t + 1) * N]
     status &= ST_FAULT_MASK
     bad = status != 0
     if bool(bad.any()):

@@ -264,15 +264,14 @@ template <typename S> __device__ __forceinline__ S geff_node(const LayerK<S> &l,
   const S t = R(1.0) - P * (sqrt_se * sqrt_se);
   return l.ksat * sqrt_se * (t * t);
 }
-// Eight consecutive safe nodes of the trapezoid (h2, g, k1 advanced as eight passes of the plain loop would).  lgar_dual.hpp
-// overloads it for dual numbers whose eight neighbouring lanes carry the SAME column with different parameter directions:
-// each lane evaluates the transcendentals of one node and the eight exchange them.
+// `nb` blocks of eight consecutive safe nodes of the trapezoid (h2, g, k1 advanced as 8 nb passes of the plain loop would).
+// lgar_dual.hpp overloads it for dual numbers whose eight neighbouring lanes carry the SAME column with different parameter
+// directions: each lane evaluates one node of a block and the eight exchange the values.
 template <typename S>
-__device__ __forceinline__ void geff_block8(const LayerK<S> &l, const S &nm1, const S &half_m, S &h2, const S &dh, const S &hdh, S &g, S &k1,
-                                            real_t<S> *xchg) {
+__device__ __forceinline__ void geff_shared_blocks(const LayerK<S> &l, const S &nm1, const S &half_m, S &h2, const S &dh, const S &hdh, S &g,
+                                                   S &k1, int nb, real_t<S> *xchg) {
   (void)xchg;
-#pragma unroll
-  for (int j = 0; j < 8; j++) {
+  for (int j = 0; j < 8 * nb; j++) {
     const S k2 = geff_node(l, nm1, half_m, h2);
     g = g + ((k1 + k2) * hdh);
     k1 = k2;
@@ -305,14 +304,49 @@ __device__ __forceinline__ void geff_nodes_cooperative(const LayerK<double> &l, 
     grp[r] = k2;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
-    for (int q = 0; q < cnt; q++) {
-      const double kq = grp[q];  // same address in every lane of the group: an LDS broadcast
-      g = g + ((k1 + kq) * hdh);
-      k1 = kq;
+    // (eight LDS reads in flight at a time: one wave alone on its SIMD has nothing else to cover their latency)
+    for (int q0 = 0; q0 < cnt; q0 += 8) {
+      double kq[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) kq[j] = grp[(q0 + j < cnt) ? q0 + j : cnt - 1];  // same address in every lane of the group: a broadcast
+#pragma unroll
+      for (int j = 0; j < 8; j++)
+        if (q0 + j < cnt) {
+          g = g + ((k1 + kq[j]) * hdh);
+          k1 = kq[j];
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // the next round's stores stay behind these loads
     __builtin_amdgcn_wave_barrier();
   }
+}
+#endif
+#ifndef LGAR_DEVSIM
+// The four two-pow evaluations that open a trapezoid -- h(Se_i), h(Se_f) (calc_h_from_se), K(Se_i), K(1) (calc_k_from_se) -- for
+// COOPERATING lanes: lane r of a group evaluates number r mod 4 and the group exchanges the results.  Both functions are
+// "pow, offset from 1, nudge, pow, finish": the lanes run ONE instruction stream with their own exponents and pick their own
+// finish, every value going through exactly the operations h_from_se / k_from_se apply to it (bit-identical results; the
+// serial chain of eight pows becomes one of two).
+__device__ __forceinline__ void geff_ends_cooperative(const LayerK<double> &l, double se_i, double se_f, double &h_i, double &h_f,
+                                                      double &k_i, double &k_sat1, int lanes, double *xchg) {
+  const int lane = (int)(threadIdx.x & 63u);
+  const int which = lane & 3;  // 0: h(Se_i), 1: h(Se_f), 2: K(Se_i), 3: K(1)
+  const bool is_h = which < 2;
+  const double se = (which == 1) ? se_f : ((which == 3) ? 1.0 : se_i);
+  const double sp = pw(se, is_h ? -l.inv_m : l.inv_m);
+  double base = is_h ? sp - 1.0 : 1.0 - sp;
+  if (fabs(base) <= 1e-8) base = base + 1e-12;
+  const double op = pw(base, is_h ? l.inv_n : l.m);
+  const double t = 1.0 - op;
+  const double mine = is_h ? (1.0 / l.alpha) * op : l.ksat * sqrt(se) * (t * t);
+  double *grp = xchg + (lane & ~(lanes - 1));
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if ((lane & (lanes - 1)) < 4) grp[which] = mine;  // lanes 0..3 of the group (lanes >= 4)
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  h_i = grp[0]; h_f = grp[1]; k_i = grp[2]; k_sat1 = grp[3];
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
 }
 #endif
 template <typename S>
@@ -320,15 +354,27 @@ __device__ __forceinline__ S geff_fused(const LayerK<S> &l, S theta1, S theta2, 
   using R = real_t<S>;
   const S se_i = se_from_theta(l, theta1);
   const S se_f = se_from_theta(l, theta2);
-  const S h_i = h_from_se(l, se_i);
-  const S h_f = h_from_se(l, se_f);
+  S h_i, h_f, k_sat1, k1;  // h(Se) of both ends; K at Se == 1 (|h| < 0.1); K(Se_i)
+  bool ends_done = false;
+#ifndef LGAR_DEVSIM
+  if constexpr (sizeof(S) == 8 && sizeof(R) == 8) {
+    if (coop >= 4 && xchg != nullptr) {
+      geff_ends_cooperative(l, se_i, se_f, h_i, h_f, k1, k_sat1, coop, xchg);
+      ends_done = true;
+    }
+  }
+#endif
+  if (!ends_done) {
+    h_i = h_from_se(l, se_i);
+    h_f = h_from_se(l, se_f);
+    k_sat1 = k_from_se(l, S(R(1.0)));
+    k1 = k_from_se(l, se_i);
+  }
   const S dh = (h_f - h_i) / R(nint);
   const S hdh = dh / R(2.0);
-  const S k_sat1 = k_from_se(l, S(R(1.0)));  // K at Se == 1 (|h| < 0.1)
   const S half_m = R(-0.5) * l.m;
   const S nm1 = l.n - R(1.0);  // n m = n - 1: a^m = (alpha h)^(n-1)
   S g = S(R(0.0));
-  S k1 = k_from_se(l, se_i);
   S h2 = h_i + dh;
   // four transcendentals per node: P = a^m = x^(n-1), a = x P, sqrt(Se) = (1+a)^(-m/2), (a/(1+a))^m = P Se
   auto node = [&](const S &h) { return geff_node(l, nm1, half_m, h); };
@@ -346,8 +392,10 @@ __device__ __forceinline__ S geff_fused(const LayerK<S> &l, S theta1, S theta2, 
   }
   int i = 0;
   if constexpr (sizeof(S) != sizeof(R) && sizeof(R) == 8) {
-    if (xchg != nullptr)
-      for (; i + 7 < n_safe; i += 8) geff_block8(l, nm1, half_m, h2, dh, hdh, g, k1, xchg);
+    if (xchg != nullptr && n_safe >= 8) {
+      geff_shared_blocks(l, nm1, half_m, h2, dh, hdh, g, k1, n_safe >> 3, xchg);
+      i = (n_safe >> 3) << 3;
+    }
   }
 #ifndef LGAR_DEVSIM
   if constexpr (sizeof(S) == 8 && sizeof(R) == 8) {

@@ -129,80 +129,111 @@ __device__ __forceinline__ Dual<R> geff_node(const LayerK<Dual<R>> &l, const Dua
   return Dual<R>(Kv, Kd);
 }
 #ifndef LGAR_DEVSIM
-// Eight nodes for eight lanes that integrate the SAME column along eight parameter directions (autograd.parameter_vjp lays
-// them side by side, LgarDims.tangent_share): the values -- and with them every branch -- are identical in the eight lanes,
-// only the tangents differ.  Lane r evaluates node r of an eight-node block and leaves the result in the wave's LDS buffer; every
-// lane then finishes all eight nodes with its own tangent.  The VALUES and their sums are those of eight passes of the plain loop,
-// bit for bit: same operations on the same operands, only computed once instead of eight times.
-// The tangent of a node is LINEAR in what differs between the eight lanes -- dx = d(alpha h), d(n-1), d(-m/2), dKsat:
+// The safe nodes of the trapezoid for eight lanes that integrate the SAME column along eight parameter directions
+// (autograd.parameter_vjp lays them side by side, LgarDims.tangent_share): the values -- and with them every branch -- are
+// identical in the eight lanes, only the tangents differ.
+//
+// VALUES.  Lane r evaluates node r of every eight-node block and leaves K in the wave's LDS buffer; every lane then adds the
+// eight values up in order.  Values and their sums are those of the plain loop bit for bit: same operations on the same
+// operands, computed once instead of eight times.
+//
+// TANGENTS.  The tangent of a node is LINEAR in what differs between the eight lanes -- dx = d(alpha h), d(n-1), d(-m/2),
+// dKsat (geff_node's logarithmic-form tangent, collected by input):
 //   dK = A1 dx + A2 d(n-1) + A3 d(-m/2) + A4 dKsat,  with (B = 2 Ksat s t P s^2, W = K - 2 B, U = -m/2 (a/A) W)
-//   A1 = ((n U - (n-1) B) / x,  A2 = ln x (U - B),  A3 = ln A W,  A4 = s t^2
-// (geff_node's logarithmic-form tangent, collected by input).  So the lane that evaluates node r also evaluates K and A1..A4,
-// and the other seven finish that node with four multiply-adds.
-__device__ __forceinline__ void geff_block8(const LayerK<Dual<double>> &l, const Dual<double> &nm1, const Dual<double> &half_m,
-                                            Dual<double> &h2, const Dual<double> &dh, const Dual<double> &hdh, Dual<double> &g,
-                                            Dual<double> &k1, double *xchg) {
+//   A1 = ((n U - (n-1) B) / x,  A2 = ln x (U - B),  A3 = ln A W,  A4 = s t^2,
+// and dx_j = d alpha h_j + alpha (dh_0 + j d(dh)) for the node with head h_j = h_0 + j dh.  The trapezoid adds every block node
+// twice (the last one once), so the tangent of the whole sum needs only SIX direction-independent sums over the nodes:
+//   sum A1 h, sum A1, sum A1 j, sum A2, sum A3, sum A4
+// Each lane accumulates them over ITS nodes while the blocks go by -- nothing but K crosses lanes per block -- and the eight
+// partial sums are combined once at the end of the call.  (Round 2 exchanged K and A1..A4 of every node and had every lane
+// redo the tangent of all eight nodes of a block: 45 LDS accesses and ~100 multiply-adds per block and lane; now 9 and ~30.)
+#define LGAR_XCHG_GROUP 9                         /* doubles per group in the K buffer: 8 + 1 of padding */
+#define LGAR_XCHG_WORDS (8 * LGAR_XCHG_GROUP + 8 * 80) /* K buffer + the end-of-call reduction area (10 values x 8 lanes per group) */
+__device__ __forceinline__ void geff_shared_blocks(const LayerK<Dual<double>> &l, const Dual<double> &nm1, const Dual<double> &half_m,
+                                                   Dual<double> &h2, const Dual<double> &dh, const Dual<double> &hdh, Dual<double> &g,
+                                                   Dual<double> &k1, int nb, double *xchg) {
   const double LN2 = 0.6931471805599453;
   const int lane = (int)(threadIdx.x & 63u);
   const int r = lane & 7;
-  // the eight heads, by the running sum of the plain loop
-  Dual<double> h[8];
-  h[0] = h2;
+  double *grp = xchg + (lane >> 3) * LGAR_XCHG_GROUP;  // padded: the eight groups of a wave read eight different bank pairs
+  double s1h = 0.0, s1 = 0.0, s1j = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0;  // my nodes' share of the six sums
+  double a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0;                        // tangent coefficients of my latest node
+  double gv = g.v, k1v = k1.v, hv = h2.v, pairsum = 0.0;
+  for (int b = 0; b < nb; b++) {
+    // the eight heads by the running sum of the plain loop; mine is number r
+    double hm = hv;
 #pragma unroll
-  for (int j = 1; j < 8; j++) h[j] = h[j - 1] + dh;
-  double hv = h[0].v;
+    for (int j = 0; j < 8; j++) {
+      hm = (j == r) ? hv : hm;
+      hv = hv + dh.v;
+    }
+    // my node: geff_node's value operations ...
+    const double xv = l.alpha.v * hm;
+    const double lg = lg2p(xv);
+    const double Pv = ex2p(nm1.v * lg);
+    const double av = xv * Pv;
+    const double Av = 1.0 + av;
+    const double l1 = lg2p(Av);
+    const double sv = ex2p(half_m.v * l1);
+    const double Ps2 = Pv * (sv * sv);
+    const double tv = 1.0 - Ps2;
+    const double ks = l.ksat.v * sv;
+    const double tt = tv * tv;
+    const double Kv = ks * tt;
+    // ... and the coefficients of its tangent
+    const double rc = fast_recip(xv * Av);  // one reciprocal serves 1/x and 1/A
+    const double B = (2.0 * (ks * tv)) * Ps2;
+    const double W = Kv - 2.0 * B;
+    const double U = (half_m.v * (av * (rc * xv))) * W;
+    a1 = (rc * Av) * ((1.0 + nm1.v) * U - nm1.v * B);
+    a2 = (LN2 * lg) * (U - B);
+    a3 = (LN2 * l1) * W;
+    a4 = sv * tt;
+    const double jj = (double)(8 * b + r);
+    s1h = fma(a1, hm, s1h); s1 += a1; s1j = fma(a1, jj, s1j); s2 += a2; s3 += a3; s4 += a4;
+    // one wave = one workgroup: LDS operations of a wave complete in order, the fences only pin the compiler
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    grp[r] = Kv;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-  for (int j = 1; j < 8; j++) hv = (r == j) ? h[j].v : hv;
-  // my node: geff_node's value operations ...
-  const double xv = l.alpha.v * hv;
-  const double lg = lg2p(xv);
-  const double Pv = ex2p(nm1.v * lg);
-  const double av = xv * Pv;
-  const double Av = 1.0 + av;
-  const double l1 = lg2p(Av);
-  const double sv = ex2p(half_m.v * l1);
-  const double Ps2 = Pv * (sv * sv);
-  const double tv = 1.0 - Ps2;
-  const double ks = l.ksat.v * sv;
-  const double tt = tv * tv;
-  const double Kv = ks * tt;
-  // ... and the coefficients of its tangent
-  const double rc = fast_recip(xv * Av);  // one reciprocal serves 1/x and 1/A
-  const double B = (2.0 * (ks * tv)) * Ps2;
-  const double W = Kv - 2.0 * B;
-  const double U = (half_m.v * (av * (rc * xv))) * W;
-  const double A1 = (rc * Av) * ((1.0 + nm1.v) * U - nm1.v * B);
-  const double A2 = (LN2 * lg) * (U - B);
-  const double A3 = (LN2 * l1) * W;
-  const double A4 = sv * tt;
-  // one wave = one workgroup: LDS operations of a wave complete in order, the fences only pin the compiler
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  xchg[0 * 64 + lane] = Kv;
-  xchg[1 * 64 + lane] = A1;
-  xchg[2 * 64 + lane] = A2;
-  xchg[3 * 64 + lane] = A3;
-  xchg[4 * 64 + lane] = A4;
+    for (int j = 0; j < 8; j++) {
+      const double kq = grp[j];  // same address in all eight lanes: an LDS broadcast
+      const double pr = k1v + kq;
+      gv = gv + (pr * hdh.v);
+      pairsum += pr;
+      k1v = kq;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // the next block's store stays behind these loads
+    __builtin_amdgcn_wave_barrier();
+  }
+  // the six sums over all block nodes, and the last node's coefficients (lane 7 of the group evaluated it)
+  double *red = xchg + 8 * LGAR_XCHG_GROUP + (lane >> 3) * (10 * 8);
+  red[0 * 8 + r] = s1h; red[1 * 8 + r] = s1; red[2 * 8 + r] = s1j; red[3 * 8 + r] = s2; red[4 * 8 + r] = s3; red[5 * 8 + r] = s4;
+  red[6 * 8 + r] = a1; red[7 * 8 + r] = a2; red[8 * 8 + r] = a3; red[9 * 8 + r] = a4;
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   __builtin_amdgcn_wave_barrier();
-  // node j of this block was evaluated by lane j of my group of eight (same address in all eight lanes: an LDS broadcast)
-  const double *grp = xchg + (lane & ~7);
-  double pr[8][5];
+  double S[6];
 #pragma unroll
-  for (int j = 0; j < 8; j++) {
+  for (int v = 0; v < 6; v++) {
+    double t = red[v * 8];
 #pragma unroll
-    for (int v = 0; v < 5; v++) pr[j][v] = grp[v * 64 + j];
+    for (int j = 1; j < 8; j++) t += red[v * 8 + j];
+    S[v] = t;
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // the next block's stores stay behind these loads
+  const double L1 = red[6 * 8 + 7], L2 = red[7 * 8 + 7], L3 = red[8 * 8 + 7], L4 = red[9 * 8 + 7];
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   __builtin_amdgcn_wave_barrier();
-#pragma unroll
-  for (int j = 0; j < 8; j++) {
-    const double xd = l.alpha.d * h[j].v + l.alpha.v * h[j].d;
-    const double Kd = pr[j][1] * xd + pr[j][2] * nm1.d + pr[j][3] * half_m.d + pr[j][4] * l.ksat.d;
-    const Dual<double> k2(pr[j][0], Kd);
-    g = g + ((k1 + k2) * hdh);
-    k1 = k2;
-  }
-  h2 = h[7] + dh;
+  // sum of dK over the block nodes and dK of the last one, for MY direction
+  const double m = (double)(8 * nb);
+  const double sumKd = l.alpha.d * S[0] + l.alpha.v * (h2.d * S[1] + dh.d * S[2]) + nm1.d * S[3] + half_m.d * S[4] + l.ksat.d * S[5];
+  const double h_last_v = hv - dh.v;  // (within an ulp of the running sum's value; it only weighs a tangent)
+  const double h_last_d = h2.d + (m - 1.0) * dh.d;
+  const double Kd_last = L1 * (l.alpha.d * h_last_v + l.alpha.v * h_last_d) + L2 * nm1.d + L3 * half_m.d + L4 * l.ksat.d;
+  // g += sum over the block terms of (k_prev + k) hdh:  k_in + 2 sum K - K_last
+  g = Dual<double>(gv, g.d + hdh.v * (k1.d + 2.0 * sumKd - Kd_last) + hdh.d * pairsum);
+  k1 = Dual<double>(k1v, Kd_last);
+  h2 = Dual<double>(hv, h2.d + m * dh.d);
 }
 #endif
 template <> __device__ __forceinline__ Dual<double> geff<Dual<double>>(const LayerK<Dual<double>> &l, Dual<double> t1,

@@ -109,7 +109,7 @@ int32_t lgar_forward(const LgarDims *dims, const LgarParams *params, LgarState *
 #ifndef LGAR_NO_TANGENT
 int32_t lgar_forward_tangent(const LgarDims *dims, const LgarParams *params, const LgarParams *direction,
                              const LgarForcing *forcing, const void *w_runoff, const void *w_perc, void *grad_out,
-                             void *tangent_runoff, int32_t *status, int32_t dtype, void *stream) {
+                             void *tangent_runoff, int32_t *status, int32_t dtype, void *stream, uint32_t *tickets) {
   int rc = check_dims(dims);
   if (rc) return rc;
   if (!params || !direction || !forcing || !grad_out || !status) return LGAR_E_ARG;
@@ -117,7 +117,7 @@ int32_t lgar_forward_tangent(const LgarDims *dims, const LgarParams *params, con
     return LGAR_E_ARG;
   if (dims->n_steps > 0 && (!forcing->precip || !forcing->pet)) return LGAR_E_ARG;
   LGAR_BY_LAYERS(launch_tangent_nl, dims, params, direction, forcing, w_runoff, w_perc, grad_out, tangent_runoff, status,
-                 dtype, (hipStream_t)stream)
+                 dtype, (hipStream_t)stream, tickets)
 }
 #endif
 

@@ -11,8 +11,6 @@
 // scalars/totals, and per forcing step 2 loads + (number of requested series) stores per column.
 #include <hip/hip_runtime.h>
 
-#include <cstdlib>
-
 #include "lgar_forward_body.hpp"
 #include "lgar_host.hpp"
 #include "lgar_launch.hpp"
@@ -171,14 +169,17 @@ static void launch_fast_kernel(KArgs<R> &a, unsigned nblocks, unsigned *ticket, 
   launch_forward_kernel<R, NL, CAP, 1>(a, nblocks, ticket, st);
 }
 
-// lanes per column for this job: LgarDims.forward_lanes when given, else the largest power of two <= 64 that keeps
-// n_columns * lanes / 64 waves within `slots` (1 for jobs that fill the chip anyway, for fp32, closed-form G, geff_mode 1)
-template <typename R> static int cooperating_lanes(const LgarDims *dims, unsigned slots) {
+// lanes per column for this job: LgarDims.forward_lanes when given, else the largest power of two <= 64 that keeps the job
+// within ONE wave per SIMD (n_columns * lanes / 64 <= simds) -- two such waves on a SIMD contend for its vector ALU in the
+// trapezoid and the gain is gone (measured: 10 000 columns x 8 lanes = 1250 waves run slower than 157 plain ones).  Fewer
+// than 8 lanes do not pay for the exchange (measured), so the answer is 1, 8, 16, 32 or 64; always 1 for fp32, closed-form G,
+// the literal mode and the mixed-precision trapezoid.
+template <typename R> static int cooperating_lanes(const LgarDims *dims, unsigned simds) {
   if (sizeof(R) != 8 || dims->search_mode == 0 || dims->use_closed_form_G || dims->geff_mode != 0) return 1;
   if (dims->forward_lanes > 0) return dims->forward_lanes;
   int lanes = 1;
-  while (lanes < WAVE && ((size_t)dims->n_columns * (size_t)(lanes * 2) + WAVE - 1) / WAVE <= (size_t)slots) lanes *= 2;
-  return lanes;
+  while (lanes < WAVE && ((size_t)dims->n_columns * (size_t)(lanes * 2) + WAVE - 1) / WAVE <= (size_t)simds) lanes *= 2;
+  return lanes >= 8 ? lanes : 1;
 }
 
 // The front-capacity chain of one lgar_forward call (see lgar_forward_body.hpp).
@@ -198,15 +199,15 @@ static int forward_typed(const LgarDims *dims, const LgarParams *params, LgarSta
   // smallest capacity that leaves room for a forcing step (one front per layer + one new front per sub-step + slack);
   // small jobs (under one wave per SIMD) gain nothing from occupancy and start at the full capacity
   const int need = NL + dims->num_subcycles + 2;
-  // Jobs that cannot fill the chip (the reference's own use is ONE column, agents/DifferentiableLGAR.py:117-125; BASELINE
-  // configs[1] is 10 000): in double precision every column gets 2..64 cooperating lanes that split the Geff trapezoid's
-  // nodes (lgar_device.hpp geff_nodes_cooperative) -- as many as keep the job within one round of the 8-slot kernel's wave
-  // slots.  Results are bit for bit those of one lane per column.
-  a.coop = cooperating_lanes<R>(dims, wave_slots(Occupancy<R, LGAR_CAP_SMALL>::waves));
+  // Jobs that cannot fill the chip (the reference's own use is ONE column, agents/DifferentiableLGAR.py:117-125): in double
+  // precision every column gets 8..64 cooperating lanes that split the Geff trapezoid's nodes and the pows that open it
+  // (lgar_device.hpp geff_nodes_cooperative / geff_ends_cooperative).  Results are bit for bit those of one lane per column.
+  // Such a job starts with the 16-slot kernel: one wave per SIMD is all it has, and the 8-slot kernel would only add a
+  // hand-over (the bundled Phillipsburg column reaches 8 fronts).
+  a.coop = cooperating_lanes<R>(dims, wave_slots(1));
   const bool tiny = grid <= 1024u && dims->search_mode != 2 && a.coop == 1;  // search_mode 2: chain forced (tests)
   int caps[3], nc = 0;
-  int first_cap = LGAR_CAP_SMALL;
-  if (a.coop > 1 && getenv("LGAR_COOP_FIRST_CAP")) first_cap = atoi(getenv("LGAR_COOP_FIRST_CAP"));  // EXPERIMENT
+  const int first_cap = (a.coop > 1 && dims->search_mode != 2) ? LGAR_CAP_MID : LGAR_CAP_SMALL;
   if (!tiny && need <= LGAR_CAP_SMALL && slots > LGAR_CAP_SMALL && first_cap <= LGAR_CAP_SMALL) caps[nc++] = LGAR_CAP_SMALL;
   if (!tiny && need <= LGAR_CAP_MID && slots > LGAR_CAP_MID && first_cap <= LGAR_CAP_MID) caps[nc++] = LGAR_CAP_MID;
   caps[nc++] = LGAR_FMAX;

@@ -17,14 +17,14 @@ template <int NL> int launch_forward_nl(const LgarDims *, const LgarParams *, Lg
                                         int32_t *status, int dtype, hipStream_t);
 template <int NL> int launch_tangent_nl(const LgarDims *, const LgarParams *, const LgarParams *direction, const LgarForcing *,
                                         const void *w_runoff, const void *w_perc, void *grad_out, void *tangent_runoff,
-                                        int32_t *status, int dtype, hipStream_t);
+                                        int32_t *status, int dtype, hipStream_t, unsigned *tickets);
 
 #define LGAR_DECLARE_NL(NL)                                                                                                    \
   extern template int launch_init_nl<NL>(const LgarDims *, const LgarParams *, LgarState *, int32_t *, int, hipStream_t);      \
   extern template int launch_forward_nl<NL>(const LgarDims *, const LgarParams *, LgarState *, const LgarForcing *,            \
                                             const LgarStepOut *, int32_t *, int, hipStream_t);                                 \
   extern template int launch_tangent_nl<NL>(const LgarDims *, const LgarParams *, const LgarParams *, const LgarForcing *,     \
-                                            const void *, const void *, void *, void *, int32_t *, int, hipStream_t);
+                                            const void *, const void *, void *, void *, int32_t *, int, hipStream_t, unsigned *);
 LGAR_DECLARE_NL(2)
 LGAR_DECLARE_NL(3)
 LGAR_DECLARE_NL(4)

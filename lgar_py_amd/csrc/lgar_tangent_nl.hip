@@ -14,56 +14,91 @@ namespace lgar {
 
 template <typename R, int NL, int CAP, int MODE> __global__ __launch_bounds__(WAVE) void lgar_tangent_kernel(TArgs<R> a) {
   __shared__ WaveLDS<Dual<R>, CAP, 1> lds;
-  __shared__ R xchg[5][WAVE];  // tangent_share: K and the four tangent coefficients of a trapezoid node, one node per lane (lgar_dual.hpp)
+  __shared__ R xchg[LGAR_XCHG_WORDS];  // tangent_share: the eight lanes of a column exchange trapezoid nodes through it (lgar_dual.hpp)
   const int lane = threadIdx.x;
-  const size_t c = (size_t)blockIdx.x * WAVE + lane;
-  if (c >= (size_t)a.N) return;
-  tangent_lane<R, NL, CAP, MODE>((const LGAR_KARG TArgs<R> *)__builtin_amdgcn_kernarg_segment_ptr(), c, lane, lds, &xchg[0][0]);
+  // the argument block is read in place (kernarg segment), see LGAR_KARG in lgar_device.hpp
+  const LGAR_KARG TArgs<R> *ap = (const LGAR_KARG TArgs<R> *)__builtin_amdgcn_kernarg_segment_ptr();
+  if (ap->pending_in != nullptr && *ap->pending_in == 0u) return;  // no column was handed over to this kernel
+  const size_t N = (size_t)ap->N;
+  unsigned *ticket = ap->ticket;
+  // 64-column blocks: the stand-alone tail first (its blocks take longest: every lane runs the whole trapezoid), then the
+  // shared groups.  With a ticket counter: persistent waves, as in the forward kernels.
+  const size_t first_tail = N - (size_t)ap->tail;
+  const unsigned tail_blocks = (unsigned)(((size_t)ap->tail + WAVE - 1) / WAVE);
+  const unsigned nblocks = tail_blocks + (unsigned)((first_tail + WAVE - 1) / WAVE);
+  for (bool first = true;; first = false) {
+    unsigned blk = blockIdx.x;
+    if (ticket != nullptr) {
+      if (lane == 0) blk = atomicAdd(ticket, 1u);
+      blk = __builtin_amdgcn_readfirstlane(blk);
+      if (blk >= nblocks) break;
+    } else if (!first) {
+      break;
+    }
+    const bool in_tail = blk < tail_blocks;
+    const size_t c = in_tail ? first_tail + (size_t)blk * WAVE + lane : (size_t)(blk - tail_blocks) * WAVE + lane;
+    if (c < (in_tail ? N : first_tail)) tangent_lane<R, NL, CAP, MODE>(ap, c, lane, lds, &xchg[0]);
+  }
 }
 
-template <typename R, int NL, int CAP, int MODE> static void launch_one(const TArgs<R> &a, unsigned grid, hipStream_t st) {
-  // the 32-slot dual-number table of a wave exceeds the 64 KiB default dynamic-LDS window only for double
+template <typename R, int NL, int CAP, int MODE>
+static void launch_one(TArgs<R> &a, unsigned nblocks, unsigned *ticket, hipStream_t st) {
+  a.ticket = ticket;
+  unsigned grid = nblocks;
+  if (ticket != nullptr) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+    const unsigned slots = (unsigned)cus * 4u;  // one wave per SIMD: the dual-number kernels hold 256 VGPRs + ~130 AGPRs
+    grid = nblocks < slots ? nblocks : slots;
+  }
   hipLaunchKernelGGL((lgar_tangent_kernel<R, NL, CAP, MODE>), dim3(grid), dim3(WAVE), 0, st, a);
 }
 
 template <typename R, int NL>
 static int tangent_typed(const LgarDims *dims, const LgarParams *params, const LgarParams *direction, const LgarForcing *forcing,
                          const void *w_runoff, const void *w_perc, void *grad_out, void *tangent_runoff, int32_t *status,
-                         hipStream_t st) {
-  const unsigned grid = (unsigned)((dims->n_columns + WAVE - 1) / WAVE);
-  TArgs<R> a{dims->n_columns, dims->n_steps, forcing_columns(dims), forcing_group(dims), dims->tangent_share, 1, 1, (const R *)params->alpha, (const R *)params->n, (const R *)params->ksat,
+                         hipStream_t st, unsigned *tickets) {
+  const unsigned tail = (unsigned)dims->tangent_plain_tail;
+  const unsigned nblocks = (tail + WAVE - 1) / WAVE + ((unsigned)dims->n_columns - tail + WAVE - 1) / WAVE;
+  if (tickets != nullptr && hipMemsetAsync(tickets, 0, LGAR_NTICKETS * sizeof(unsigned), st) != hipSuccess) return LGAR_E_LAUNCH;
+  TArgs<R> a{dims->n_columns, dims->n_steps, forcing_columns(dims), forcing_group(dims), dims->tangent_share, front_slots(dims),
+             (int)tail, nullptr, nullptr, nullptr, 1, 1, (const R *)params->alpha, (const R *)params->n, (const R *)params->ksat,
              (const R *)params->theta_e, (const R *)params->theta_r, (const R *)params->thickness,
              (const R *)direction->alpha, (const R *)direction->n, (const R *)direction->ksat,
              (const R *)forcing->precip, (const R *)forcing->pet, (const R *)w_runoff, (const R *)w_perc,
              (R *)grad_out, (R *)tangent_runoff, status, make_glob<R>(dims)};
   if (dims->search_mode == 0) {
-    launch_one<R, NL, LGAR_FMAX, 0>(a, grid, st);
+    launch_one<R, NL, LGAR_FMAX, 0>(a, nblocks, tickets, st);
     return launch_status();
   }
-  const bool chain = (NL + dims->num_subcycles + 2 <= LGAR_CAP_SMALL) && (grid > 1024u || dims->search_mode == 2);
+  const bool chain = (NL + dims->num_subcycles + 2 <= LGAR_CAP_SMALL) && (nblocks > 1024u || dims->search_mode == 2);
   if (chain) {
     a.chain_first = 1; a.chain_last = 0;
-    launch_one<R, NL, LGAR_CAP_SMALL, 1>(a, grid, st);
+    a.pending_out = tickets ? tickets + 4 : nullptr;
+    launch_one<R, NL, LGAR_CAP_SMALL, 1>(a, nblocks, tickets, st);
     int rc = launch_status();
     if (rc) return rc;
     a.chain_first = 0; a.chain_last = 1;
+    a.pending_in = a.pending_out;
+    a.pending_out = nullptr;
   }
-  launch_one<R, NL, LGAR_FMAX, 1>(a, grid, st);
+  launch_one<R, NL, LGAR_FMAX, 1>(a, nblocks, tickets ? tickets + 1 : nullptr, st);
   return launch_status();
 }
 
 template <int NL>
 int launch_tangent_nl(const LgarDims *dims, const LgarParams *params, const LgarParams *direction, const LgarForcing *forcing,
                       const void *w_runoff, const void *w_perc, void *grad_out, void *tangent_runoff, int32_t *status,
-                      int dtype, hipStream_t st) {
+                      int dtype, hipStream_t st, unsigned *tickets) {
   if (dtype == LGAR_F64)
-    return tangent_typed<double, NL>(dims, params, direction, forcing, w_runoff, w_perc, grad_out, tangent_runoff, status, st);
+    return tangent_typed<double, NL>(dims, params, direction, forcing, w_runoff, w_perc, grad_out, tangent_runoff, status, st, tickets);
   if (dtype == LGAR_F32)
-    return tangent_typed<float, NL>(dims, params, direction, forcing, w_runoff, w_perc, grad_out, tangent_runoff, status, st);
+    return tangent_typed<float, NL>(dims, params, direction, forcing, w_runoff, w_perc, grad_out, tangent_runoff, status, st, tickets);
   return LGAR_E_ARG;
 }
 
 template int launch_tangent_nl<LGAR_NL>(const LgarDims *, const LgarParams *, const LgarParams *, const LgarForcing *,
-                                        const void *, const void *, void *, void *, int32_t *, int, hipStream_t);
+                                        const void *, const void *, void *, void *, int32_t *, int, hipStream_t, unsigned *);
 
 }  // namespace lgar

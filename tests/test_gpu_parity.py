@@ -494,3 +494,50 @@ def test_single_step_transitions_from_injected_reference_states(name):
         assert _rel(res["depth"][:n, c], g["fronts"][k, :n, 0]).max() <= 1e-6, k
         assert _rel(res["theta"][:n, c], g["fronts"][k, :n, 1]).max() <= 1e-6, k
         assert (res["layer"][:n, c] == g["front_layer"][k, :n]).all() and (res["to_bottom"][:n, c] == g["front_bottom"][k, :n]).all()
+
+
+@pytest.mark.parametrize("lanes", [8, 64])
+@pytest.mark.parametrize("name", ["phil_hourly_3000", "synth1_phil", "manyfronts_pulse_84", "five_layer_phil_500",
+                                  "two_layer_synth1", "six_layer_synth1", "frozen07_phil_hourly_400"])
+def test_cooperating_lanes_reproduce_one_lane_per_column(name, lanes):
+    """LgarDims.forward_lanes: small fp64 jobs give every column 8..64 lanes that split the Geff trapezoid's nodes (and the
+    pows that open it) between them.  Every per-step output and the final front tables are those of one lane per column BIT
+    FOR BIT; run totals, which are summed per kernel of the capacity chain, to 1e-13."""
+    import lgar_py_amd as lg
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    ncol = 5
+    res = {}
+    for k in (1, lanes):
+        eng = _engine(g, ncol, torch.float64, forward_lanes=k)
+        pr, pe = _forcing(g, ncol)
+        out = eng.forward(pr, pe, series=lg.ACC_NAMES, check=False)
+        res[k] = (out, eng)
+    a, ea = res[1]
+    b, eb = res[lanes]
+    for nm in lg.ACC_NAMES:
+        assert torch.equal(a[nm], b[nm]), nm
+    for t in ("depth", "theta", "psi", "k", "dzdt", "flags", "n_fronts", "status", "scalars"):
+        assert torch.equal(getattr(ea, t), getattr(eb, t)), t
+    assert torch.allclose(ea.totals, eb.totals, rtol=1e-13, atol=1e-13)
+
+
+def test_cooperating_lanes_on_distinct_columns_and_the_default_choice():
+    """200 different columns: the library's own choice (16 lanes for this size) and a forced 8 reproduce one lane per column."""
+    import lgar_py_amd as lg
+    from lgar_py_amd import workloads as W
+    N = 200
+    P = W.perturbed_columns(N, seed=21)
+    f = W.synth1_forcing()
+    pr = torch.tensor(f[:, 0:1] * W.forcing_scale(N, seed=22)[None, :])
+    pe = torch.zeros_like(pr)
+    outs = []
+    for k in (1, 0, 8):
+        eng = lg.LgarEngine(P["alpha"], P["n"], P["ksat"], P["theta_e"], P["theta_r"], P["thickness"], dt_h=300.0 / 3600.0,
+                            ponded_depth_max=0.0, dtype=torch.float64, forward_lanes=k)
+        out = eng.forward(pr, pe, series=("runoff", "infiltration", "ending_volume"), check=False)
+        outs.append((out, eng.status.clone(), eng.theta.clone(), eng.n_fronts.clone()))
+    for o, st, th, nf in outs[1:]:
+        for nm in ("runoff", "infiltration", "ending_volume"):
+            assert torch.equal(o[nm], outs[0][0][nm]), nm
+        assert torch.equal(st, outs[0][1]) and torch.equal(th, outs[0][2]) and torch.equal(nf, outs[0][3])
+    assert int((outs[0][1] != 0).sum()) > 0  # the ensemble contains columns the reference faults on: same flags
