@@ -38,32 +38,51 @@ def alg_bytes_per_col_step(elem, T, L=3, fmax=16):
     return 4 * elem + b_col / T
 
 
-def _profile_records():
+def library_fingerprint():
+    """Content fingerprint of the HIP library's sources, headers and flags (lgar_py_amd/build.py): what a committed profile
+    is checked against."""
+    from lgar_py_amd import build as B
+    return B._fingerprint()
+
+
+def _matching_profile(N, T, dtype):
+    """The latest committed PMC record (profiles/*/traffic*.json) taken on exactly this workload, with whether it was taken
+    with THIS library build."""
+    best = None
     pdir = os.path.join(ROOT, "profiles")
     for r in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
-        f = os.path.join(pdir, r, "traffic.json")
-        if os.path.exists(f):
-            with open(f) as fh:
-                yield r, json.load(fh)
+        if not os.path.isdir(os.path.join(pdir, r)):
+            continue
+        for fn in sorted(os.listdir(os.path.join(pdir, r))):
+            if fn.startswith("traffic") and fn.endswith(".json"):
+                with open(os.path.join(pdir, r, fn)) as fh:
+                    t = json.load(fh)
+                if (t.get("columns"), t.get("timesteps"), t.get("dtype")) == (N, T, dtype):
+                    best = dict(t, source="profiles/%s/%s" % (r, fn))
+    if best is not None:
+        best["same_library"] = best.get("library_fingerprint") == library_fingerprint()
+    return best
 
 
 def measured_traffic(N, T, dtype):
-    """HBM bytes per launch from the committed PMC passes (profiles/*/traffic.json, latest round wins), when they were
-    taken on exactly this workload; FETCH_SIZE corrected x2 as MI355X_MICROARCH.md prescribes for gfx950."""
-    best = None
-    for _, t in _profile_records():
-        if (t.get("columns"), t.get("timesteps"), t.get("dtype")) == (N, T, dtype):
-            best = (2 * t["FETCH_SIZE_KB"] + t["WRITE_SIZE_KB"]) * 1024
-    return best
+    """(HBM bytes per launch, provenance) from the committed PMC passes, FETCH_SIZE corrected x2 as MI355X_MICROARCH.md
+    prescribes for gfx950 -- or (None, reason): the counters come from separate rocprofv3 --pmc passes, not from this run, so
+    the figure is only reported when the profile was taken on exactly this workload AND with this library build."""
+    t = _matching_profile(N, T, dtype)
+    if t is None:
+        return None, "no committed profile of this workload (%d columns x %d steps, %s)" % (N, T, dtype)
+    if not t["same_library"]:
+        return None, "%s was taken with another build of the library (fingerprint %s, this build %s)" % (
+            t["source"], str(t.get("library_fingerprint"))[:12], library_fingerprint()[:12])
+    return (2 * t["FETCH_SIZE_KB"] + t["WRITE_SIZE_KB"]) * 1024, "%s (separate rocprofv3 --pmc passes on this library build)" % t["source"]
 
 
 def measured_valu(N, T, dtype):
-    """Compute-side counters from the committed PMC passes (profiles/*/traffic.json 'valu' block), same workload only."""
-    best = None
-    for r, t in _profile_records():
-        if (t.get("columns"), t.get("timesteps"), t.get("dtype")) == (N, T, dtype) and "valu" in t:
-            best = dict(t["valu"], source="profiles/%s/traffic.json" % r)
-    return best
+    """Compute-side counters from the committed PMC passes ('valu' block), same workload and same library build only."""
+    t = _matching_profile(N, T, dtype)
+    if t is None or "valu" not in t or not t["same_library"]:
+        return None
+    return dict(t["valu"], source=t["source"])
 
 
 def cpu_model():
@@ -243,7 +262,7 @@ def valu_probe_record(dev):
 
     from lgar_py_amd import _capi
     lib = _capi.load()
-    ops = {"v_exp_f32": 0, "v_log_f32": 1, "v_fma_f32": 4, "geff_mix": 16}
+    ops = {"v_exp_f32": 0, "v_log_f32": 1, "v_fma_f32": 4, "geff_mix": 16, "v_fma_f64": 12}
     rec = {}
     st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
@@ -418,6 +437,7 @@ def main():
         # (include/lgar.h), named as rocprofv3 prints it
         kname = "lgar_forward_kernel<%s, 3, %d, 1>" % ("float" if elem == 4 else "double",
                                                         lg._capi.CAP_SMALL if N > 65536 else lg._capi.FMAX)
+        traffic, traffic_note = measured_traffic(N, T, args.dtype)
         line = {
             "metric": "column-timesteps/sec", "value": units / elapsed, "unit": "column-timesteps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(args.steps, 1),
@@ -434,8 +454,7 @@ def main():
                        "collective": None if not dist_on else ("%s all-reduce of basin runoff [T], group of %d%s" % (
                            backend, world, " (LGAR_FORCE_DIST=1)" if world == 1 else ""))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(N, T, args.dtype),
-                         "traffic_note": "bytes per launch from separate rocprofv3 --pmc passes (profiles/*/traffic.json), not live",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                          "algorithmic_bytes_per_launch": b_alg * N * T,
                          "kernel": kname, "kernel_ms": kern_ms, "alg_bytes_per_column_timestep": b_alg,
                          "note": "path is VALU bound, not HBM bound (~1e3 flop/B; see valu_roofline and DESIGN.md); "
@@ -444,6 +463,7 @@ def main():
             "basin_runoff_total_cm": float(basin.sum().item()),
         }
         pmc = measured_valu(N, T, args.dtype)
+        probe = {}
         if world == 1 and not args.no_extras:
             # compute-side roof, live: what this chip's vector ALU sustains vs what the Geff trapezoid (the dominant
             # instruction stream: 5 v_log/v_exp per node, 121 nodes per call) got out of it
@@ -474,6 +494,7 @@ def main():
             # the parity-bearing precision on the same workload (1e-6 vs the reference holds in fp64)
             if args.dtype == "f32":
                 e64, p64, q64, _ = make_workload("synth1", N, torch.float64, rank)
+                e64.geff_wave_calls()  # reset the counter
                 ms = []
                 for _ in range(3):
                     e64.reset()
@@ -487,6 +508,20 @@ def main():
                 subs["fp64"] = {"value": N * T / (ms * 1e-3), "unit": "column-timesteps/s", "kernel_ms": ms, "columns": N,
                                 "timesteps": T, "dtype": "f64", "workload": "same synth_1 ensemble, fp64 (parity precision)",
                                 "roofline_frac_hbm": alg_bytes_per_col_step(8, T) * N * T / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                # compute side of the parity precision: the fused fp64 trapezoid node is 93 vector instructions
+                # (profiles/*/isa_census.txt: 2 log2 + 2 exp2 by polynomial, no hardware transcendental), all of them at the
+                # v_fma_f64 issue rate except two v_rcp_f64 at a quarter of it (profiles/r02/valu_probe_f64_helpers.jsonl)
+                calls64 = e64.geff_wave_calls() / 3.0
+                node_insts, node_issue_slots = 93, 93 + 2 * 3
+                if probe.get("v_fma_f64"):
+                    subs["fp64"]["valu_roofline"] = {
+                        "bound": "valu-issue", "unit": "wave-instructions/s", "peak_v_fma_f64": probe["v_fma_f64"],
+                        "geff_wave_calls_per_launch": calls64, "vector_instructions_per_trapezoid_node": node_insts,
+                        "achieved_geff_instructions": calls64 * 121 * node_insts / (ms * 1e-3),
+                        "frac_of_fma64_issue_peak": calls64 * 121 * node_issue_slots / (ms * 1e-3) / probe["v_fma_f64"],
+                        "note": "the trapezoid's fp64 instruction stream (in v_fma_f64 issue slots) per second of the WHOLE kernel "
+                                "time over the chip's measured v_fma_f64 issue rate: the rest of the kernel time is the column "
+                                "physics outside the trapezoid and lanes idled by divergence"}
                 del e64, p64, q64
                 # fp64 column state with the fp32 hardware transcendentals inside the Geff trapezoid (LgarDims.geff_mode = 1):
                 # run totals of every column within 2e-6 of the native fp64 kernels', identical fault flags (tests/test_gpu_mixed.py)

@@ -21,16 +21,26 @@ def test_algorithmic_bytes_match_survey():
     assert abs(b.alg_bytes_per_col_step(8, 144) - (32 + 1712 / 144)) < 1e-12 and abs(b.alg_bytes_per_col_step(8, 144) - 43.4) < 0.6
 
 
-def test_committed_pmc_lookup():
+def test_committed_pmc_lookup(monkeypatch):
+    """roofline.traffic comes from a committed profile only when that profile was taken on exactly this workload AND with this
+    library build (content fingerprint); otherwise it is null with the reason."""
     b = _bench()
-    t = b.measured_traffic(1048576, 144, "f32")
     alg = b.alg_bytes_per_col_step(4, 144) * 1048576 * 144
-    # measured HBM traffic of the timed kernel stays within 15 % of the 3.33 GB algorithmic figure (the residue is the
-    # scratch write-back of ~1 spilled dword per column-step at 128 VGPRs): no wasted re-reads
-    assert t is not None and 1.5e9 < t < 1.15 * alg
-    assert b.measured_traffic(12345, 144, "f32") is None
+    t, why = b.measured_traffic(12345, 144, "f32")
+    assert t is None and "no committed profile" in why
+    rec = b._matching_profile(1048576, 144, "f32")
+    assert rec is not None and rec["source"].startswith("profiles/r0")
+    # as if the profile had been taken with this very build: the figure is reported and stays within 15 % of the 3.33 GB
+    # algorithmic figure (no wasted re-reads)
+    monkeypatch.setattr(b, "library_fingerprint", lambda: rec.get("library_fingerprint"))
+    t, why = b.measured_traffic(1048576, 144, "f32")
+    assert t is not None and 1.5e9 < t < 1.15 * alg and rec["source"] in why
     v = b.measured_valu(1048576, 144, "f32")
-    assert v is not None and 0.5 < v["busy_frac"] <= 1.0 and v["source"].startswith("profiles/r02")
+    assert v is not None and 0.5 < v["busy_frac"] <= 1.0 and v["source"] == rec["source"]
+    # ... and with any other build it is not
+    monkeypatch.setattr(b, "library_fingerprint", lambda: "0" * 64)
+    t, why = b.measured_traffic(1048576, 144, "f32")
+    assert t is None and "another build" in why and b.measured_valu(1048576, 144, "f32") is None
 
 
 def test_cpu_baseline_leg_runs_on_a_tiny_sample(monkeypatch):

@@ -358,6 +358,10 @@ def test_wet_hourly_ensemble_faults_where_the_oracle_does():
         assert _rel(tot[:8, ok], acc[:8, ok], 1e-3).max() <= 1e-6, mode
 
 
+# columns of W.ensemble_columns(512, seed=3) on which kernel and oracle may disagree about a fault, per search mode
+WIDE_ENSEMBLE_BORDERLINE = {0: set(), 1: set()}
+
+
 def test_wide_parameter_ensemble_vs_oracle_fp64():
     """BASELINE configs[4]'s parameter ranges (alpha in [0.0015, 0.015], n in [1.1, 3], Ksat in [0.01, 5]) under the
     synth_1 storm: kernel vs oracle per column; the same columns leave the reference's domain of validity."""
@@ -377,8 +381,11 @@ def test_wide_parameter_ensemble_vs_oracle_fp64():
         out = eng.forward(torch.tensor(pr), torch.tensor(pe), series=("runoff",), check=False)
         gst = eng.status.cpu().numpy()
         agree = ((st != 0) == (gst != 0))
-        # exact agreement expected; one borderline column in 512 may flip on a last-bit pow difference (device vs glibc)
-        assert (~agree).sum() <= 1, (mode, int((~agree).sum()))
+        # Exact agreement is the rule.  The only disagreements admitted are the columns NAMED here: ones whose top layer
+        # saturates (psi -> 0), where the reference's own decision (an isclose tie at 1e-8, the Se > 1 fault of insert_water)
+        # hinges on the last bit of pow -- device vs glibc.  A new disagreement fails the test.
+        flipped = set(int(i) for i in np.nonzero(~agree)[0])
+        assert flipped <= WIDE_ENSEMBLE_BORDERLINE[mode], (mode, sorted(flipped))
         ok = (st == 0) & (gst == 0)
         assert ok.mean() > 0.5
         tot = eng.totals.cpu().numpy()

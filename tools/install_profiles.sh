@@ -3,7 +3,7 @@
 # derived files (dev tool, runs in the build container).  usage: tools/install_profiles.sh gpurun_out/<prof dir> profiles/r02
 SRC=$1; DST=$2
 mkdir -p "$DST/pmc"
-for wl in f32 f64 tan; do
+for wl in f32 f64 tan mix; do
   [ -f "$SRC/${wl}_stats/p_kernel_stats.csv" ] && cp "$SRC/${wl}_stats/p_kernel_stats.csv" "$DST/${wl}_kernel_stats.csv"
   for pass in valu mix wait fetch write; do
     [ -f "$SRC/${wl}_$pass/p_counter_collection.csv" ] && cp "$SRC/${wl}_$pass/p_counter_collection.csv" "$DST/pmc/${wl}_${pass}_counter_collection.csv"
@@ -12,4 +12,7 @@ done
 python tools/pmc_summary.py "$SRC" > "$DST/pmc_summary.txt" 2>/dev/null
 python tools/make_traffic_json.py "$SRC" "$DST/traffic.json" "lgar_forward_kernel<float, 3, 8, 1>" 1048576 144 f32
 python tools/make_traffic_json.py "$SRC" "$DST/traffic_f64.json" "lgar_forward_kernel<double, 3, 8, 1>" 1048576 144 f64
+python tools/make_traffic_json.py "$SRC" "$DST/traffic_mixed.json" "lgar_forward_kernel<double, 3, 8, 3>" 1048576 144 f64mix mix_
+python tools/make_traffic_json.py "$SRC" "$DST/traffic_tangent.json" "lgar_tangent_kernel<double, 3, 8, 1>" 900000 144 f64tan tan_
+cp "$SRC/library_fingerprint" "$DST/library_fingerprint" 2>/dev/null
 python tools/isa_count.py "$DST/isa_census.txt"

@@ -1,5 +1,6 @@
 """profiles/<round>/traffic.json from the rocprofv3 passes of tools/pmc_passes.sh (dev tool).
-usage: make_traffic_json.py PROF_DIR OUT_JSON [kernel-substring] [columns] [timesteps] [dtype]"""
+usage: make_traffic_json.py PROF_DIR OUT_JSON [kernel-substring] [columns] [timesteps] [dtype] [csv-prefix]
+PROF_DIR/library_fingerprint (written by pmc_passes.sh on the GPU box) records which library build the counters belong to."""
 import collections
 import csv
 import glob
@@ -11,7 +12,11 @@ kern = sys.argv[3] if len(sys.argv) > 3 else "lgar_forward_kernel<float, 3, 8, 1
 cols = int(sys.argv[4]) if len(sys.argv) > 4 else 1 << 20
 T = int(sys.argv[5]) if len(sys.argv) > 5 else 144
 dtype = sys.argv[6] if len(sys.argv) > 6 else "f32"
-prefix = {"f32": "f32_", "f64": "f64_"}[dtype]
+prefix = sys.argv[7] if len(sys.argv) > 7 else {"f32": "f32_", "f64": "f64_"}[dtype]
+import os
+fp = None
+if os.path.exists(os.path.join(prof, "library_fingerprint")):
+    fp = open(os.path.join(prof, "library_fingerprint")).read().strip()
 acc = collections.defaultdict(list)
 for f in glob.glob(prof + "/" + prefix + "*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
@@ -38,7 +43,7 @@ valu = {
     "definition": "medians over the launches of separate rocprofv3 --pmc passes (tools/pmc_passes.sh); busy_frac = 4*SQ_ACTIVE_INST_VALU "
                   "/ (1024 SIMDs * GRBM_GUI_ACTIVE/8 XCDs); per wave-step = per 64 columns x 1 forcing step",
 }
-rec = {"columns": cols, "timesteps": T, "dtype": dtype, "FETCH_SIZE_KB": med.get("FETCH_SIZE"), "WRITE_SIZE_KB": med.get("WRITE_SIZE"),
+rec = {"columns": cols, "timesteps": T, "dtype": dtype, "library_fingerprint": fp, "FETCH_SIZE_KB": med.get("FETCH_SIZE"), "WRITE_SIZE_KB": med.get("WRITE_SIZE"),
        "note": "FETCH_SIZE is doubled by bench.py as MI355X_MICROARCH.md prescribes for gfx950", "valu": valu}
 json.dump(rec, open(out, "w"), indent=1)
 print(json.dumps(rec, indent=1))
