@@ -101,10 +101,12 @@ typedef struct {
                                 forcing column (c / G) % forcing_columns; n_columns must be a multiple of G * forcing_columns.
                                 (The differentiable path puts the G parameter directions of one column in adjacent lanes:
                                 they take the same branches, so a wavefront diverges over 64 / G columns instead of 64.) */
-  int32_t tangent_share;     /* lgar_forward_tangent only.  0: every column stands alone.  8: the caller guarantees that each
-                                aligned group of 8 consecutive columns is ONE soil column (identical parameters and forcing)
-                                with 8 different directions; the 8 lanes then share the transcendentals of the Geff trapezoid
-                                (fp64 fast modes; ignored elsewhere).  n_columns must be a multiple of 8. */
+  int32_t tangent_share;     /* lgar_forward_tangent only.  0: every column stands alone.  W = 2..32: the caller guarantees that
+                                each group of W consecutive columns is ONE soil column (identical parameters and forcing) with W
+                                different directions; the W lanes then share the Geff trapezoid -- each evaluates every W-th node,
+                                and the tangent of the whole sum comes from five direction-independent sums (fp64 fast modes;
+                                ignored elsewhere).  n_columns must be a multiple of W; a wavefront carries floor(64 / W) such
+                                groups (W = 9, the 3 x L parameters of a 3-layer column: 7 groups, one idle lane). */
   int32_t geff_mode;         /* 0: the Geff trapezoid (lgar/green_ampt.py:45-84) in the precision of `dtype`.  1 (LGAR_F64 fast
                                 modes only; ignored elsewhere): mixed precision -- column state, branches and mass bookkeeping
                                 stay fp64, the two heads and the two end nodes of the trapezoid stay fp64, its 119 interior
@@ -113,10 +115,7 @@ typedef struct {
                                 jobs under one wave per SIMD get 8..64 cooperating lanes per column, which split the nodes of
                                 the Geff trapezoid between them (results bit for bit those of one lane per column); 1: one lane
                                 per column whatever the job size; 2, 4, .. 64: that many */
-  int32_t tangent_plain_tail; /* lgar_forward_tangent with tangent_share = 8 only.  The LAST this-many columns stand alone (no
-                                sharing): column c of that tail reads forcing / weight column (c - first tail column) %
-                                forcing_columns.  n_columns - tangent_plain_tail must be a multiple of 64.  (A backward pass over
-                                3 x L = 9 parameters rides as 8 shared directions + 1 in the tail of ONE launch.) */
+  int32_t reserved4;
 } LgarDims;
 
 /* Per-column soil parameters, each [n_layers][n_columns].  Replaces dpLGAR.alpha/.n/.ksat
@@ -196,8 +195,7 @@ int32_t lgar_forward(const LgarDims *dims, const LgarParams *params, LgarState *
  * (w_* may be NULL).  Line-search offsets are constants w.r.t. the parameters, as in the reference
  * (Layer.py:277-288,683-696).  tangent_runoff ([n_steps][n_columns]) may be NULL.
  * tickets: NULL or device uint32[LGAR_NTICKETS] (zeroed by the library on the stream): with it the kernels run as one
- * resident wave per wave slot of the chip, each pulling 64-column blocks (the stand-alone tail first: its blocks take
- * longest) until none is left. */
+ * resident wave per wave slot of the chip, each pulling blocks of columns until none is left. */
 int32_t lgar_forward_tangent(const LgarDims *dims, const LgarParams *params, const LgarParams *direction,
                              const LgarForcing *forcing, const void *w_runoff, const void *w_perc,
                              void *grad_out, void *tangent_runoff, int32_t *status, int32_t dtype, void *stream,

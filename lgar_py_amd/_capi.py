@@ -32,7 +32,7 @@ class LgarDims(C.Structure):
                 ("dt_h", C.c_double), ("initial_psi", C.c_double), ("ponded_depth_max", C.c_double),
                 ("wilting_point_psi", C.c_double), ("frozen_factor", C.c_double), ("giuh", C.c_double * GMAX),
                 ("iter_cap", C.c_int64), ("forcing_columns", C.c_int32), ("forcing_group", C.c_int32),
-                ("tangent_share", C.c_int32), ("geff_mode", C.c_int32), ("forward_lanes", C.c_int32), ("tangent_plain_tail", C.c_int32)]
+                ("tangent_share", C.c_int32), ("geff_mode", C.c_int32), ("forward_lanes", C.c_int32), ("reserved4", C.c_int32)]
 
 
 class LgarParams(C.Structure):

@@ -21,9 +21,9 @@ KINDS = ("alpha", "n", "ksat")
 # the directions of a backward pass ride side by side as extra columns of a tangent launch (column-major: column
 # c * D + b integrates column c's parameters perturbed in direction b, so that a column's directions sit in adjacent lanes);
 # forcing and weights are NOT replicated -- the kernels broadcast them (LgarDims.forcing_columns / forcing_group).  Above this
-# many (column, direction) pairs the directions go in groups; in fp64 fast modes groups of 8 share the Geff trapezoid.
+# many (column, direction) pairs the directions go in groups; in fp64 fast modes the lanes of a column share the Geff trapezoid.
 BATCH_DIRECTIONS_MAX_COLUMNS = 1 << 23
-SHARE_MIN_COLUMNS = 8192  # 8 lanes per column x 8192 columns = one wave on every SIMD of the chip
+SHARE_MIN_LANES = 65536  # columns x directions: one wave on every SIMD of the chip
 
 
 def parameter_vjp(eng, precip, pet, w_runoff, w_perc, wanted, check=True):
@@ -40,34 +40,16 @@ def parameter_vjp(eng, precip, pet, w_runoff, w_perc, wanted, check=True):
         return out, status
     group = max(1, min(D, BATCH_DIRECTIONS_MAX_COLUMNS // max(N, 1)))
     d = eng.dims
-    # fp64 fast modes: groups of exactly 8 directions let the 8 lanes of a column share the transcendentals of the Geff
-    # trapezoid (LgarDims.tangent_share); directions left over after the last full group ride in the SAME launch as a
-    # stand-alone tail (LgarDims.tangent_plain_tail: 3 x L = 9 parameters -> 8 shared + 1 tail, one launch, no second tail of
-    # half-empty rounds)
-    # (only when the shared launch fills the chip: a small job is bound by the latency of ONE wave)
-    share8 = (eng.dtype == torch.float64 and d.search_mode != 0 and not d.use_closed_form_G and group >= 8
-              and N >= SHARE_MIN_COLUMNS)
-    tail_ok = share8 and N % 8 == 0 and (D % 8) * N + 8 * N <= BATCH_DIRECTIONS_MAX_COLUMNS
-    if share8:
-        group = 8
-    chunks = [wanted[g0:g0 + group] for g0 in range(0, D, group)]
-    tails = []
-    if tail_ok and len(chunks) >= 2 and len(chunks[-1]) < 8:
-        tails = chunks.pop()  # the left-over directions: the tail of the last shared launch
-
-    def big_engine(rep):
-        return LgarEngine(rep(eng.alpha), rep(eng.n), rep(eng.ksat), rep(eng.theta_e), rep(eng.theta_r), rep(eng.thickness),
-                          dt_h=d.dt_h, num_subcycles=d.num_subcycles, initial_psi=d.initial_psi,
-                          ponded_depth_max=d.ponded_depth_max, wilting_point_psi=d.wilting_point_psi,
-                          frozen_factor=d.frozen_factor, nint=d.nint, giuh_ordinates=tuple(d.giuh[i] for i in range(d.n_giuh)),
-                          dtype=eng.dtype, device=eng.device, iter_cap=d.iter_cap, search_mode=d.search_mode,
-                          bottom_mode=d.bottom_mode, use_closed_form_G=bool(d.use_closed_form_G), front_slots=eng.front_slots,
-                          with_state=False)
-
-    for ci, part in enumerate(chunks):
+    # fp64 fast modes: the directions of a column sit in adjacent lanes that SHARE the Geff trapezoid (LgarDims.tangent_share =
+    # group width; the tangent of the trapezoid needs only five direction-independent sums, so all 3 x L directions of a column
+    # fit one group: 9 lanes for three layers, seven groups per wavefront)
+    # (only when the launch fills the chip: a small job is bound by the latency of ONE wave)
+    share = (eng.dtype == torch.float64 and d.search_mode != 0 and not d.use_closed_form_G and 2 <= group <= 32
+             and N * group >= SHARE_MIN_LANES)
+    for g0 in range(0, D, group):
+        part = wanted[g0:g0 + group]
         Dg = len(part)
-        tail = tails if (tails and ci == len(chunks) - 1) else []
-        if Dg == 1 and not tail:
+        if Dg == 1:
             kind, l = part[0]
             dmat = torch.zeros(L, N, dtype=eng.dtype, device=eng.device)
             dmat[l] = 1.0
@@ -75,24 +57,23 @@ def parameter_vjp(eng, precip, pet, w_runoff, w_perc, wanted, check=True):
             status |= st
             continue
         # column n's Dg directions sit in ADJACENT lanes (column n * Dg + b): they follow the same branches, so a wavefront
-        # diverges over 64 / Dg columns instead of 64; the kernel reads forcing / weight column c // Dg (forcing_group).
-        # Tail directions follow direction-major (column Dg * N + t * N + n: direction t of column n).
-        Nt = len(tail) * N
-        rep = lambda t: torch.cat([t.repeat_interleave(Dg, dim=1), t.repeat(1, len(tail))], dim=1) if tail else t.repeat_interleave(Dg, dim=1)
-        big = big_engine(rep)
-        dirs = {k: torch.zeros(L, Dg * N + Nt, dtype=eng.dtype, device=eng.device) for k in KINDS}
+        # diverges over 64 / Dg columns instead of 64; the kernel reads forcing / weight column c // Dg (forcing_group)
+        rep = lambda t: t.repeat_interleave(Dg, dim=1)
+        big = LgarEngine(rep(eng.alpha), rep(eng.n), rep(eng.ksat), rep(eng.theta_e), rep(eng.theta_r), rep(eng.thickness),
+                         dt_h=d.dt_h, num_subcycles=d.num_subcycles, initial_psi=d.initial_psi,
+                         ponded_depth_max=d.ponded_depth_max, wilting_point_psi=d.wilting_point_psi,
+                         frozen_factor=d.frozen_factor, nint=d.nint, giuh_ordinates=tuple(d.giuh[i] for i in range(d.n_giuh)),
+                         dtype=eng.dtype, device=eng.device, iter_cap=d.iter_cap, search_mode=d.search_mode,
+                         bottom_mode=d.bottom_mode, use_closed_form_G=bool(d.use_closed_form_G), front_slots=eng.front_slots,
+                         with_state=False)
+        dirs = {k: torch.zeros(L, Dg * N, dtype=eng.dtype, device=eng.device) for k in KINDS}
         for b, (kind, l) in enumerate(part):
-            dirs[kind][l, b:Dg * N:Dg] = 1.0
-        for t, (kind, l) in enumerate(tail):
-            dirs[kind][l, Dg * N + t * N:Dg * N + (t + 1) * N] = 1.0
+            dirs[kind][l, b::Dg] = 1.0
         g, _, st = big.tangent(dirs, precip, pet, w_runoff=w_runoff, w_perc=w_perc, forcing_group=Dg,  # forcing / weights broadcast by the kernel
-                               share=8 if (share8 and Dg == 8) else 0, plain_tail=Nt)
+                               share=Dg if share else 0)
         for b, key in enumerate(part):
-            out[key] = g[b:Dg * N:Dg].contiguous()
-            status |= st[b:Dg * N:Dg]
-        for t, key in enumerate(tail):
-            out[key] = g[Dg * N + t * N:Dg * N + (t + 1) * N].contiguous()
-            status |= st[Dg * N + t * N:Dg * N + (t + 1) * N]
+            out[key] = g[b::Dg].contiguous()
+            status |= st[b::Dg]
     status &= ST_FAULT_MASK
     bad = status != 0
     if bool(bad.any()):

@@ -264,14 +264,14 @@ template <typename S> __device__ __forceinline__ S geff_node(const LayerK<S> &l,
   const S t = R(1.0) - P * (sqrt_se * sqrt_se);
   return l.ksat * sqrt_se * (t * t);
 }
-// `nb` blocks of eight consecutive safe nodes of the trapezoid (h2, g, k1 advanced as 8 nb passes of the plain loop would).
-// lgar_dual.hpp overloads it for dual numbers whose eight neighbouring lanes carry the SAME column with different parameter
-// directions: each lane evaluates one node of a block and the eight exchange the values.
+// `nb` blocks of W consecutive safe nodes of the trapezoid (h2, g, k1 advanced as W nb passes of the plain loop would).
+// lgar_dual.hpp overloads it for dual numbers whose W neighbouring lanes carry the SAME column with different parameter
+// directions: each lane evaluates one node of a block and the W exchange the values.
 template <typename S>
 __device__ __forceinline__ void geff_shared_blocks(const LayerK<S> &l, const S &nm1, const S &half_m, S &h2, const S &dh, const S &hdh, S &g,
-                                                   S &k1, int nb, real_t<S> *xchg) {
+                                                   S &k1, int nb, int W, real_t<S> *xchg) {
   (void)xchg;
-  for (int j = 0; j < 8 * nb; j++) {
+  for (int j = 0; j < W * nb; j++) {
     const S k2 = geff_node(l, nm1, half_m, h2);
     g = g + ((k1 + k2) * hdh);
     k1 = k2;
@@ -392,9 +392,9 @@ __device__ __forceinline__ S geff_fused(const LayerK<S> &l, S theta1, S theta2, 
   }
   int i = 0;
   if constexpr (sizeof(S) != sizeof(R) && sizeof(R) == 8) {
-    if (xchg != nullptr && n_safe >= 8) {
-      geff_shared_blocks(l, nm1, half_m, h2, dh, hdh, g, k1, n_safe >> 3, xchg);
-      i = (n_safe >> 3) << 3;
+    if (xchg != nullptr && coop >= 2 && n_safe >= coop) {  // coop: the W lanes that share this column (LgarDims.tangent_share)
+      geff_shared_blocks(l, nm1, half_m, h2, dh, hdh, g, k1, n_safe / coop, coop, xchg);
+      i = (n_safe / coop) * coop;
     }
   }
 #ifndef LGAR_DEVSIM
@@ -788,7 +788,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
   S k_deepest;
   bool new_front_frozen;
   bool count_geff = false;              // measurement: count wave-level Geff evaluations in the unused upper bits of `status`
-  int share_lanes = 0;                  // tangent kernels: 8 = my seven neighbours carry this same column (other directions);
+  int share_lanes = 0;                  // tangent kernels: W = 2..32 adjacent lanes carry this same column (other directions);
                                         // forward kernels: 2..64 = that many adjacent lanes carry this very column (small jobs)
   R *xchg = nullptr;                    // ... and the wave's LDS buffer they exchange trapezoid nodes through
   int cap = FMAX;                       // fronts this column may hold: min(kernel capacity, rows of the state arrays)
@@ -809,7 +809,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
       return G->closed_form ? geff_closed<S, POL>(lk, theta1, theta2) : geff_literal<S, POL>(lk, theta1, theta2, G->nint);
     }
     if constexpr (sizeof(S) != sizeof(R) && sizeof(R) == 8 && MODE != 0) {
-      if (share_lanes == 8 && !G->closed_form) return geff_fused<S>(lk, theta1, theta2, G->nint, xchg);
+      if (share_lanes >= 2 && !G->closed_form) return geff_fused<S>(lk, theta1, theta2, G->nint, xchg, share_lanes);
     }
     if constexpr (MODE == 1 && sizeof(S) == 8 && sizeof(R) == 8) {  // plain double: cooperating lanes (small jobs)
       if (share_lanes > 1 && !G->closed_form) return geff_fused<S>(lk, theta1, theta2, G->nint, xchg, share_lanes);

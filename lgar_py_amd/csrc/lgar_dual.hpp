@@ -129,41 +129,47 @@ __device__ __forceinline__ Dual<R> geff_node(const LayerK<Dual<R>> &l, const Dua
   return Dual<R>(Kv, Kd);
 }
 #ifndef LGAR_DEVSIM
-// The safe nodes of the trapezoid for eight lanes that integrate the SAME column along eight parameter directions
-// (autograd.parameter_vjp lays them side by side, LgarDims.tangent_share): the values -- and with them every branch -- are
-// identical in the eight lanes, only the tangents differ.
+// The safe nodes of the trapezoid for W lanes that integrate the SAME column along W parameter directions
+// (autograd.parameter_vjp lays them side by side, LgarDims.tangent_share = W): the values -- and with them every branch --
+// are identical in the W lanes, only the tangents differ.
 //
-// VALUES.  Lane r evaluates node r of every eight-node block and leaves K in the wave's LDS buffer; every lane then adds the
-// eight values up in order.  Values and their sums are those of the plain loop bit for bit: same operations on the same
-// operands, computed once instead of eight times.
+// VALUES.  Lane r evaluates node r of every W-node block and leaves K in the wave's LDS buffer; every lane then adds the W
+// values up in order.  Values and their sums are those of the plain loop bit for bit: same operations on the same operands,
+// computed once instead of W times.
 //
-// TANGENTS.  The tangent of a node is LINEAR in what differs between the eight lanes -- dx = d(alpha h), d(n-1), d(-m/2),
-// dKsat (geff_node's logarithmic-form tangent, collected by input):
-//   dK = A1 dx + A2 d(n-1) + A3 d(-m/2) + A4 dKsat,  with (B = 2 Ksat s t P s^2, W = K - 2 B, U = -m/2 (a/A) W)
-//   A1 = ((n U - (n-1) B) / x,  A2 = ln x (U - B),  A3 = ln A W,  A4 = s t^2,
+// TANGENTS.  The tangent of a node is LINEAR in what differs between the lanes -- dx = d(alpha h), d(n-1), d(-m/2), dKsat
+// (geff_node's logarithmic-form tangent, collected by input):
+//   dK = A1 dx + A2 d(n-1) + A3 d(-m/2) + A4 dKsat,  with (B = 2 Ksat s t P s^2, W' = K - 2 B, U = -m/2 (a/A) W')
+//   A1 = ((n U - (n-1) B) / x,  A2 = ln x (U - B),  A3 = ln A W',  A4 = s t^2,
 // and dx_j = d alpha h_j + alpha (dh_0 + j d(dh)) for the node with head h_j = h_0 + j dh.  The trapezoid adds every block node
-// twice (the last one once), so the tangent of the whole sum needs only SIX direction-independent sums over the nodes:
-//   sum A1 h, sum A1, sum A1 j, sum A2, sum A3, sum A4
-// Each lane accumulates them over ITS nodes while the blocks go by -- nothing but K crosses lanes per block -- and the eight
-// partial sums are combined once at the end of the call.  (Round 2 exchanged K and A1..A4 of every node and had every lane
-// redo the tangent of all eight nodes of a block: 45 LDS accesses and ~100 multiply-adds per block and lane; now 9 and ~30.)
-#define LGAR_XCHG_GROUP 9                         /* doubles per group in the K buffer: 8 + 1 of padding */
-#define LGAR_XCHG_WORDS (8 * LGAR_XCHG_GROUP + 8 * 80) /* K buffer + the end-of-call reduction area (10 values x 8 lanes per group) */
-__device__ __forceinline__ void geff_shared_blocks(const LayerK<Dual<double>> &l, const Dual<double> &nm1, const Dual<double> &half_m,
-                                                   Dual<double> &h2, const Dual<double> &dh, const Dual<double> &hdh, Dual<double> &g,
-                                                   Dual<double> &k1, int nb, double *xchg) {
+// twice (the last one once), so the tangent of the whole sum needs only FIVE direction-independent sums over the nodes:
+//   sum A1, sum A1 j, sum A2, sum A3, sum A4        (dx_j = c0 + j c1: both constants of the lane)
+// Each lane accumulates them over ITS nodes while the blocks go by -- nothing but K crosses lanes per block -- and the W
+// partial sums are combined once at the end of the call.  Because nothing else is direction-dependent, ALL 3 x L directions of
+// a column fit one group (W = 9 for three layers: 7 groups per wavefront), instead of 8 sharing lanes plus a ninth direction
+// that ran the whole trapezoid alone.  (Round 2 exchanged K and A1..A4 of every node and had every lane redo the tangent of
+// all eight nodes of a block: 45 LDS accesses and ~100 multiply-adds per block and lane; now W + 1 and ~30.)
+#define LGAR_XCHG_GROUP 33  /* doubles per group in the K buffer: up to 32 lanes + 1 of padding (groups on different bank pairs) */
+#define LGAR_XCHG_RED 9     /* values per lane in the end-of-call reduction area: five sums + the last node's four coefficients */
+#define LGAR_XCHG_WORDS (64 + 32 + 64 * LGAR_XCHG_RED + 64) /* K buffer (<= 32 groups x padded stride < 128) + reduction area */
+// WC: the group width as a compile-time constant (loops over the lanes of a group unroll), or 0: run-time width `Wrt`
+template <int WC>
+__device__ __forceinline__ void geff_shared_blocks_w(const LayerK<Dual<double>> &l, const Dual<double> &nm1, const Dual<double> &half_m,
+                                                     Dual<double> &h2, const Dual<double> &dh, const Dual<double> &hdh, Dual<double> &g,
+                                                     Dual<double> &k1, int nb, int Wrt, double *xchg) {
+  const int W = WC ? WC : Wrt;
   const double LN2 = 0.6931471805599453;
   const int lane = (int)(threadIdx.x & 63u);
-  const int r = lane & 7;
-  double *grp = xchg + (lane >> 3) * LGAR_XCHG_GROUP;  // padded: the eight groups of a wave read eight different bank pairs
-  double s1h = 0.0, s1 = 0.0, s1j = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0;  // my nodes' share of the six sums
+  const int grp_id = lane / W, r = lane - grp_id * W;
+  double *grp = xchg + grp_id * (W + 1);  // padded: neighbouring groups start on different bank pairs
+  double s1 = 0.0, s1j = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0;  // my nodes' share of the five sums
   double a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0;                        // tangent coefficients of my latest node
   double gv = g.v, k1v = k1.v, hv = h2.v, pairsum = 0.0;
   for (int b = 0; b < nb; b++) {
-    // the eight heads by the running sum of the plain loop; mine is number r
+    // the W heads by the running sum of the plain loop; mine is number r
     double hm = hv;
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
+    for (int j = 0; j < W; j++) {
       hm = (j == r) ? hv : hm;
       hv = hv + dh.v;
     }
@@ -183,57 +189,90 @@ __device__ __forceinline__ void geff_shared_blocks(const LayerK<Dual<double>> &l
     // ... and the coefficients of its tangent
     const double rc = fast_recip(xv * Av);  // one reciprocal serves 1/x and 1/A
     const double B = (2.0 * (ks * tv)) * Ps2;
-    const double W = Kv - 2.0 * B;
-    const double U = (half_m.v * (av * (rc * xv))) * W;
+    const double Wk = Kv - 2.0 * B;
+    const double U = (half_m.v * (av * (rc * xv))) * Wk;
     a1 = (rc * Av) * ((1.0 + nm1.v) * U - nm1.v * B);
     a2 = (LN2 * lg) * (U - B);
-    a3 = (LN2 * l1) * W;
+    a3 = (LN2 * l1) * Wk;
     a4 = sv * tt;
-    const double jj = (double)(8 * b + r);
-    s1h = fma(a1, hm, s1h); s1 += a1; s1j = fma(a1, jj, s1j); s2 += a2; s3 += a3; s4 += a4;
-    // one wave = one workgroup: LDS operations of a wave complete in order, the fences only pin the compiler
+    const double jj = (double)(W * b + r);
+    s1 += a1; s1j = fma(a1, jj, s1j); s2 += a2; s3 += a3; s4 += a4;
+    // one wave = one workgroup: LDS operations of a wave complete in order, the fences only pin the compiler.
+    // (A software pipeline -- block b's values read before block b+1's node is evaluated and added up after it -- was built
+    // and measured: 4 ms SLOWER on the 100 000-column backward pass, 26 more AGPRs of shuffling for latency that is a small
+    // part of a block by now.)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     grp[r] = Kv;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
+    if constexpr (WC != 0) {
+      double kq[WC ? WC : 1];
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-      const double kq = grp[j];  // same address in all eight lanes: an LDS broadcast
-      const double pr = k1v + kq;
-      gv = gv + (pr * hdh.v);
-      pairsum += pr;
-      k1v = kq;
+      for (int j = 0; j < WC; j++) kq[j] = grp[j];  // same address in all lanes of the group: an LDS broadcast
+#pragma unroll
+      for (int j = 0; j < WC; j++) {
+        const double pr = k1v + kq[j];
+        gv = gv + (pr * hdh.v);
+        pairsum += pr;
+        k1v = kq[j];
+      }
+    } else {
+      for (int j0 = 0; j0 < W; j0 += 8) {  // eight reads in flight at a time
+        double kq[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) kq[j] = grp[(j0 + j < W) ? j0 + j : W - 1];
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+          if (j0 + j < W) {
+            const double pr = k1v + kq[j];
+            gv = gv + (pr * hdh.v);
+            pairsum += pr;
+            k1v = kq[j];
+          }
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // the next block's store stays behind these loads
     __builtin_amdgcn_wave_barrier();
   }
-  // the six sums over all block nodes, and the last node's coefficients (lane 7 of the group evaluated it)
-  double *red = xchg + 8 * LGAR_XCHG_GROUP + (lane >> 3) * (10 * 8);
-  red[0 * 8 + r] = s1h; red[1 * 8 + r] = s1; red[2 * 8 + r] = s1j; red[3 * 8 + r] = s2; red[4 * 8 + r] = s3; red[5 * 8 + r] = s4;
-  red[6 * 8 + r] = a1; red[7 * 8 + r] = a2; red[8 * 8 + r] = a3; red[9 * 8 + r] = a4;
+  // the five sums over all block nodes, and the last node's coefficients (the group's last lane evaluated it)
+  double *red = xchg + 96 + grp_id * (W * LGAR_XCHG_RED + 1);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  red[0 * W + r] = s1; red[1 * W + r] = s1j; red[2 * W + r] = s2; red[3 * W + r] = s3; red[4 * W + r] = s4;
+  red[5 * W + r] = a1; red[6 * W + r] = a2; red[7 * W + r] = a3; red[8 * W + r] = a4;
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   __builtin_amdgcn_wave_barrier();
-  double S[6];
+  double S[5];
 #pragma unroll
-  for (int v = 0; v < 6; v++) {
-    double t = red[v * 8];
+  for (int v = 0; v < 5; v++) {
+    double t = red[v * W];
 #pragma unroll
-    for (int j = 1; j < 8; j++) t += red[v * 8 + j];
+    for (int j = 1; j < W; j++) t += red[v * W + j];
     S[v] = t;
   }
-  const double L1 = red[6 * 8 + 7], L2 = red[7 * 8 + 7], L3 = red[8 * 8 + 7], L4 = red[9 * 8 + 7];
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  const double L1 = red[5 * W + W - 1], L2 = red[6 * W + W - 1], L3 = red[7 * W + W - 1], L4 = red[8 * W + W - 1];
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // a later call's stores stay behind these loads
   __builtin_amdgcn_wave_barrier();
   // sum of dK over the block nodes and dK of the last one, for MY direction
-  const double m = (double)(8 * nb);
-  const double sumKd = l.alpha.d * S[0] + l.alpha.v * (h2.d * S[1] + dh.d * S[2]) + nm1.d * S[3] + half_m.d * S[4] + l.ksat.d * S[5];
-  const double h_last_v = hv - dh.v;  // (within an ulp of the running sum's value; it only weighs a tangent)
-  const double h_last_d = h2.d + (m - 1.0) * dh.d;
-  const double Kd_last = L1 * (l.alpha.d * h_last_v + l.alpha.v * h_last_d) + L2 * nm1.d + L3 * half_m.d + L4 * l.ksat.d;
+  const double m = (double)(W * nb);
+  // d(alpha h_j) = c0 + j c1 with the node's head h_j = h_0 + j dh.  c0 and c1 are formed FIRST: for the alpha direction
+  // alpha h does not depend on alpha at all (h = f(Se) / alpha), the two products in each cancel, and they must cancel before
+  // anything is summed -- grouped by input instead (d alpha sum A1 h + alpha sum A1 dh_j) the big sums cancel to ~1e-8 of the
+  // gradient (measured against the unshared launch; now ~1e-12).
+  const double c0 = l.alpha.d * h2.v + l.alpha.v * h2.d;
+  const double c1 = l.alpha.d * dh.v + l.alpha.v * dh.d;
+  const double sumKd = c0 * S[0] + c1 * S[1] + nm1.d * S[2] + half_m.d * S[3] + l.ksat.d * S[4];
+  const double Kd_last = L1 * (c0 + (m - 1.0) * c1) + L2 * nm1.d + L3 * half_m.d + L4 * l.ksat.d;
   // g += sum over the block terms of (k_prev + k) hdh:  k_in + 2 sum K - K_last
   g = Dual<double>(gv, g.d + hdh.v * (k1.d + 2.0 * sumKd - Kd_last) + hdh.d * pairsum);
   k1 = Dual<double>(k1v, Kd_last);
   h2 = Dual<double>(hv, h2.d + m * dh.d);
+}
+__device__ __forceinline__ void geff_shared_blocks(const LayerK<Dual<double>> &l, const Dual<double> &nm1, const Dual<double> &half_m,
+                                                   Dual<double> &h2, const Dual<double> &dh, const Dual<double> &hdh, Dual<double> &g,
+                                                   Dual<double> &k1, int nb, int W, double *xchg) {
+  // 9 = the 3 x L parameters of a three-layer column (BASELINE configs[4]); other widths run the generic loops
+  if (W == 9) geff_shared_blocks_w<9>(l, nm1, half_m, h2, dh, hdh, g, k1, nb, W, xchg);
+  else geff_shared_blocks_w<0>(l, nm1, half_m, h2, dh, hdh, g, k1, nb, W, xchg);
 }
 #endif
 template <> __device__ __forceinline__ Dual<double> geff<Dual<double>>(const LayerK<Dual<double>> &l, Dual<double> t1,

@@ -38,12 +38,9 @@ inline int check_dims(const LgarDims *d) {
   if (d->nint <= 0 || d->num_subcycles <= 0 || d->n_steps < 0 || d->n_steps >= (1 << 23)) return LGAR_E_ARG;
   if (d->search_mode < 0 || d->search_mode > 2) return LGAR_E_ARG;
   if (d->front_slots < 0 || d->front_slots > LGAR_FMAX || (d->front_slots > 0 && d->front_slots < d->n_layers + 1)) return LGAR_E_ARG;
-  if (d->tangent_plain_tail < 0 || d->tangent_plain_tail > d->n_columns) return LGAR_E_ARG;
-  if (d->forcing_columns < 0 || d->forcing_group < 0 || (d->n_columns - d->tangent_plain_tail) % forcing_group(d) != 0) return LGAR_E_ARG;
-  if (d->forcing_columns > 0 && ((d->n_columns - d->tangent_plain_tail) / forcing_group(d)) % d->forcing_columns != 0) return LGAR_E_ARG;
-  if (d->forcing_columns > 0 && d->tangent_plain_tail % d->forcing_columns != 0) return LGAR_E_ARG;
-  if (d->tangent_share != 0 && (d->tangent_share != 8 || d->n_columns % 8 != 0)) return LGAR_E_ARG;
-  if (d->tangent_plain_tail > 0 && (d->tangent_share != 8 || (d->n_columns - d->tangent_plain_tail) % 64 != 0)) return LGAR_E_ARG;
+  if (d->forcing_columns < 0 || d->forcing_group < 0 || d->n_columns % forcing_group(d) != 0) return LGAR_E_ARG;
+  if (d->forcing_columns > 0 && (d->n_columns / forcing_group(d)) % d->forcing_columns != 0) return LGAR_E_ARG;
+  if (d->tangent_share != 0 && (d->tangent_share < 2 || d->tangent_share > 32 || d->n_columns % d->tangent_share != 0)) return LGAR_E_ARG;
   if (d->geff_mode < 0 || d->geff_mode > 1) return LGAR_E_ARG;
   if (d->forward_lanes < 0 || d->forward_lanes > 64 || (d->forward_lanes & (d->forward_lanes - 1)) != 0) return LGAR_E_ARG;
   if (!(d->dt_h > 0.0)) return LGAR_E_ARG;

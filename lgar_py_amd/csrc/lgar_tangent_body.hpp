@@ -17,9 +17,8 @@ namespace lgar {
 
 template <typename R> struct TArgs {
   int N, T, Nf, Fg;  // Nf, Fg: columns of the forcing and weight arrays and group: column c reads column (c / Fg) % Nf
-  int share;         // 8: each aligned group of 8 columns is one soil column along 8 directions (LgarDims.tangent_share)
+  int share;         // W = 2..32: each group of W consecutive columns is one soil column along W directions (LgarDims.tangent_share)
   int F;             // LgarDims.front_slots: the most fronts a column may hold, as in the forward kernels (same overflow flag)
-  int tail;          // LgarDims.tangent_plain_tail: the last `tail` columns stand alone; tail column c reads forcing column (c - (N - tail)) % Nf
   unsigned *ticket;  // null, or this launch's work counter (persistent waves)
   const unsigned *pending_in;  // null, or how many columns the first kernel of the chain handed over
   unsigned *pending_out;       // null, or where this kernel counts the columns it hands over
@@ -61,15 +60,14 @@ __device__ __forceinline__ void tangent_lane(const LGAR_KARG TArgs<R> *ap, size_
     P.cum[k] = (k == 0) ? P.thick[0] : P.cum[(k > 0) ? k - 1 : 0] + P.thick[k];
   }
   Column<S, NL, FMAX, MODE> col(P, &ap->G, make_view<S, FMAX>(&lds.f[0][0][0], &lds.fl[0][0], lane));
-  const size_t first_tail = N - (size_t)a.tail;  // columns from here on stand alone
-  col.share_lanes = (xchg != nullptr && c < first_tail) ? a.share : 0;
+  col.share_lanes = (xchg != nullptr) ? a.share : 0;
   col.xchg = xchg;
   col.cap = FMAX < a.F ? FMAX : a.F;
   col.init_state();
   R grad = R(0);
   bool handed_over = false;
   const size_t Nf = (size_t)a.Nf;
-  const size_t cf = (c >= first_tail) ? (c - first_tail) % Nf : ((Nf == N) ? c : (c / (size_t)a.Fg) % Nf);
+  const size_t cf = (Nf == N) ? c : (c / (size_t)a.Fg) % Nf;
   for (int t = 0; t < a.T; t++) {
     const size_t o = (size_t)t * Nf + cf;
     if (!a.chain_last && col.nf + a.G.nsub > FMAX) {

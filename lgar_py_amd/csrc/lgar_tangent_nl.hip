@@ -12,20 +12,21 @@
 
 namespace lgar {
 
+__host__ __device__ inline unsigned columns_per_block(int share) { return share >= 2 ? (unsigned)((WAVE / share) * share) : (unsigned)WAVE; }
+
 template <typename R, int NL, int CAP, int MODE> __global__ __launch_bounds__(WAVE) void lgar_tangent_kernel(TArgs<R> a) {
   __shared__ WaveLDS<Dual<R>, CAP, 1> lds;
-  __shared__ R xchg[LGAR_XCHG_WORDS];  // tangent_share: the eight lanes of a column exchange trapezoid nodes through it (lgar_dual.hpp)
+  __shared__ R xchg[LGAR_XCHG_WORDS];  // tangent_share: the lanes of a column exchange trapezoid nodes through it (lgar_dual.hpp)
   const int lane = threadIdx.x;
   // the argument block is read in place (kernarg segment), see LGAR_KARG in lgar_device.hpp
   const LGAR_KARG TArgs<R> *ap = (const LGAR_KARG TArgs<R> *)__builtin_amdgcn_kernarg_segment_ptr();
   if (ap->pending_in != nullptr && *ap->pending_in == 0u) return;  // no column was handed over to this kernel
   const size_t N = (size_t)ap->N;
   unsigned *ticket = ap->ticket;
-  // 64-column blocks: the stand-alone tail first (its blocks take longest: every lane runs the whole trapezoid), then the
-  // shared groups.  With a ticket counter: persistent waves, as in the forward kernels.
-  const size_t first_tail = N - (size_t)ap->tail;
-  const unsigned tail_blocks = (unsigned)(((size_t)ap->tail + WAVE - 1) / WAVE);
-  const unsigned nblocks = tail_blocks + (unsigned)((first_tail + WAVE - 1) / WAVE);
+  // A block = the columns of one wavefront: 64, or -- W lanes sharing a column (tangent_share) -- floor(64 / W) groups of W.
+  // With a ticket counter: persistent waves, as in the forward kernels.
+  const unsigned cpb = columns_per_block(ap->share);
+  const unsigned nblocks = (unsigned)((N + cpb - 1) / cpb);
   for (bool first = true;; first = false) {
     unsigned blk = blockIdx.x;
     if (ticket != nullptr) {
@@ -35,9 +36,8 @@ template <typename R, int NL, int CAP, int MODE> __global__ __launch_bounds__(WA
     } else if (!first) {
       break;
     }
-    const bool in_tail = blk < tail_blocks;
-    const size_t c = in_tail ? first_tail + (size_t)blk * WAVE + lane : (size_t)(blk - tail_blocks) * WAVE + lane;
-    if (c < (in_tail ? N : first_tail)) tangent_lane<R, NL, CAP, MODE>(ap, c, lane, lds, &xchg[0]);
+    const size_t c = (size_t)blk * cpb + lane;
+    if ((unsigned)lane < cpb && c < N) tangent_lane<R, NL, CAP, MODE>(ap, c, lane, lds, &xchg[0]);
   }
 }
 
@@ -59,11 +59,11 @@ template <typename R, int NL>
 static int tangent_typed(const LgarDims *dims, const LgarParams *params, const LgarParams *direction, const LgarForcing *forcing,
                          const void *w_runoff, const void *w_perc, void *grad_out, void *tangent_runoff, int32_t *status,
                          hipStream_t st, unsigned *tickets) {
-  const unsigned tail = (unsigned)dims->tangent_plain_tail;
-  const unsigned nblocks = (tail + WAVE - 1) / WAVE + ((unsigned)dims->n_columns - tail + WAVE - 1) / WAVE;
+  const unsigned cpb = columns_per_block(dims->tangent_share);
+  const unsigned nblocks = ((unsigned)dims->n_columns + cpb - 1) / cpb;
   if (tickets != nullptr && hipMemsetAsync(tickets, 0, LGAR_NTICKETS * sizeof(unsigned), st) != hipSuccess) return LGAR_E_LAUNCH;
   TArgs<R> a{dims->n_columns, dims->n_steps, forcing_columns(dims), forcing_group(dims), dims->tangent_share, front_slots(dims),
-             (int)tail, nullptr, nullptr, nullptr, 1, 1, (const R *)params->alpha, (const R *)params->n, (const R *)params->ksat,
+             nullptr, nullptr, nullptr, 1, 1, (const R *)params->alpha, (const R *)params->n, (const R *)params->ksat,
              (const R *)params->theta_e, (const R *)params->theta_r, (const R *)params->thickness,
              (const R *)direction->alpha, (const R *)direction->n, (const R *)direction->ksat,
              (const R *)forcing->precip, (const R *)forcing->pet, (const R *)w_runoff, (const R *)w_perc,

@@ -250,45 +250,33 @@ class LgarEngine:
         if bool((status_host != 0).any()):
             self.check_status()
 
-    def tangent(self, direction, precip, pet, w_runoff=None, w_perc=None, want_series=False, forcing_group=1, share=0,
-                plain_tail=0):
+    def tangent(self, direction, precip, pet, w_runoff=None, w_perc=None, want_series=False, forcing_group=1, share=0):
         """Forward-mode tangent from a FRESH state (set_internal_states) over the whole forcing series.
 
         direction: {"alpha" | "n" | "ksat": [L, N] tensor} -- the parameter perturbation (missing = 0).
         precip / pet / w_runoff / w_perc: [T, N], or all [T, Nf] with forcing_group * Nf dividing N (column c uses column
         (c // forcing_group) % Nf of each).
-        share=8: each aligned group of 8 columns is ONE soil column along 8 directions (the lanes share the Geff trapezoid);
-        plain_tail: with share=8, the last plain_tail columns stand alone instead (tail column c reads forcing / weight column
-        (c - first tail column) % Nf): a backward pass over 9 parameters is 8 shared directions + 1 in the tail of one launch.
+        share = W (2..32): each group of W consecutive columns is ONE soil column along W directions; the W lanes share the
+        Geff trapezoid (LgarDims.tangent_share).
         Returns (grad[N], tangent_runoff[T, N] or None, status[N]) with
         grad[c] = sum_t w_runoff[t, c] * d runoff_t[c] + w_perc[t, c] * d percolation_t[c].  status != 0 marks columns whose
         tangent integration faulted (their grad entry is not a gradient): callers must check it (autograd.parameter_vjp does)."""
         prep = lambda t: None if t is None else torch.as_tensor(t).to(self.device, self.dtype).contiguous()
         precip, pet, w_runoff, w_perc = prep(precip), prep(pet), prep(w_runoff), prep(w_perc)
-        plain_tail = int(plain_tail)
-        n_grouped = self.N - plain_tail
-        if plain_tail < 0 or plain_tail > self.N or (plain_tail and (share != 8 or n_grouped % 64 != 0
-                                                                     or plain_tail % precip.shape[1] != 0)):
-            raise LgarError("plain_tail needs share=8, n_columns - plain_tail a multiple of 64 and plain_tail a multiple of the "
-                            "forcing columns")
-        g = max(1, int(forcing_group))
-        if (precip.shape != pet.shape or precip.dim() != 2 or n_grouped % g != 0 or (n_grouped // g) % precip.shape[1] != 0):
-            raise LgarError("forcing must be [T, Nf] with forcing_group * Nf dividing the %d grouped columns; got %s / %s, "
-                            "forcing_group %d" % (n_grouped, tuple(precip.shape), tuple(pet.shape), g))
-        self.dims.forcing_columns, self.dims.forcing_group = precip.shape[1], g
-        self.dims.tangent_plain_tail = plain_tail
-        if share not in (0, 8) or (share == 8 and n_grouped % 8 != 0):
-            raise LgarError("share must be 0 or 8 (with the grouped columns a multiple of 8)")
-        if share == 8:
-            # the kernel takes the caller's word that each aligned group of 8 columns is one soil column; a violation would
+        self._set_forcing_layout(precip, pet, forcing_group)
+        share = int(share)
+        if share != 0 and (not 2 <= share <= 32 or self.N % share != 0):
+            raise LgarError("share must be 0 or 2..32 (with n_columns a multiple of it)")
+        if share:
+            # the kernel takes the caller's word that each group of `share` columns is one soil column; a violation would
             # give silently wrong gradients, so the wrapper checks (six small reductions)
             for t in (self.alpha, self.n, self.ksat, self.theta_e, self.theta_r, self.thickness):
-                g8 = t[:, :n_grouped].reshape(t.shape[0], -1, 8)
-                if not bool((g8 == g8[:, :, :1]).all()):
-                    raise LgarError("share=8 needs identical soil parameters within each aligned group of 8 columns")
-            if forcing_group % 8 != 0 and precip.shape[1] != 1:
-                raise LgarError("share=8 needs the 8 columns of a group to read the same forcing column (forcing_group a "
-                                "multiple of 8, or one forcing column for all)")
+                gw = t.reshape(t.shape[0], -1, share)
+                if not bool((gw == gw[:, :, :1]).all()):
+                    raise LgarError("share=%d needs identical soil parameters within each group of %d columns" % (share, share))
+            if forcing_group % share != 0 and precip.shape[1] != 1:
+                raise LgarError("share=%d needs the columns of a group to read the same forcing column (forcing_group a "
+                                "multiple of it, or one forcing column for all)" % share)
         self.dims.tangent_share = int(share)
         for nm, w in (("w_runoff", w_runoff), ("w_perc", w_perc)):
             if w is not None and w.shape != precip.shape:
@@ -310,7 +298,6 @@ class LgarEngine:
             rc = self.lib.lgar_forward_tangent(C.byref(self.dims), C.byref(self._params), C.byref(dstruct), C.byref(fo),
                                                ptr(w_runoff), ptr(w_perc), grad.data_ptr(), ptr(ser), st.data_ptr(),
                                                self._dt, self._stream(), tickets.data_ptr())
-        self.dims.tangent_plain_tail = 0
         _capi.check(rc, "lgar_forward_tangent")
         return grad, ser, st
 

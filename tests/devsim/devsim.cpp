@@ -106,7 +106,7 @@ template <typename R, int NL>
 int tangent_typed(const LgarDims *d, const LgarParams *p, const LgarParams *dir, const LgarForcing *f, const void *wr, const void *wp,
                   void *grad, void *tser, int32_t *status) {
   TArgs<R> a{d->n_columns, d->n_steps, d->forcing_columns > 0 ? d->forcing_columns : d->n_columns / (d->forcing_group > 1 ? d->forcing_group : 1),
-             d->forcing_group > 1 ? d->forcing_group : 1, 0 /* one lane: nothing to share */, d->front_slots > 0 ? d->front_slots : LGAR_FMAX, 0, nullptr, nullptr, nullptr, 1, 1, (const R *)p->alpha, (const R *)p->n, (const R *)p->ksat, (const R *)p->theta_e,
+             d->forcing_group > 1 ? d->forcing_group : 1, 0 /* one lane: nothing to share */, d->front_slots > 0 ? d->front_slots : LGAR_FMAX, nullptr, nullptr, nullptr, 1, 1, (const R *)p->alpha, (const R *)p->n, (const R *)p->ksat, (const R *)p->theta_e,
              (const R *)p->theta_r, (const R *)p->thickness, (const R *)dir->alpha, (const R *)dir->n, (const R *)dir->ksat,
              (const R *)f->precip, (const R *)f->pet, (const R *)wr, (const R *)wp, (R *)grad, (R *)tser, status, make_glob<R>(d)};
   if (d->search_mode == 0) { run_tangent<R, NL, LGAR_FMAX, 0>(a); return 0; }

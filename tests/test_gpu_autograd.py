@@ -40,11 +40,11 @@ def test_gradients_match_reference_autograd(name, mode, shared, monkeypatch):
     """Fixtures from the reference's own loss.backward(): nominal Phillipsburg, 4 layers, +-10 % ensemble members
     (grad_synth1_pert*), wide-range ensemble members (grad_wide*: BASELINE configs[4]'s parameter ranges) and a column
     with up to 19 fronts (grad_manyfronts_60: more than the 8-slot tangent kernel holds -> capacity chain).  Both ways the
-    backward pass lays out its directions: all of a column's directions in one launch (small jobs), and eight of them
-    sharing the Geff trapezoid + the rest in a second launch (jobs that fill the chip; forced here)."""
+    backward pass lays out its directions: every lane on its own (small jobs), and the 3 x L directions of a column sharing
+    the Geff trapezoid in one group of lanes (jobs that fill the chip; forced here: groups of 6, 9, 12, 15 and 18 lanes)."""
     import lgar_py_amd.autograd as A
     from lgar_py_amd.autograd import lgar_series
-    monkeypatch.setattr(A, "SHARE_MIN_COLUMNS", 1 if shared else 1 << 30)
+    monkeypatch.setattr(A, "SHARE_MIN_LANES", 1 if shared else 1 << 30)
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     N = 3
     P, pr, pe, ekw = _setup(g, N, search_mode=mode)
@@ -319,34 +319,44 @@ def test_fp32_gradients_close_to_reference():
         assert np.abs(got - ref).max() <= 2e-2 * np.abs(ref).max(), (k, got, ref)
 
 
-def test_shared_tangent_launch_equals_plain_launch_and_rejects_mixed_groups():
-    """LgarDims.tangent_share = 8: eight direction-lanes of a column share the Geff trapezoid.  Gradients equal the plain
-    launch's to rounding (the values are bit-identical, the tangents are summed in another order), and the wrapper refuses
-    groups whose eight columns are not one soil column."""
+@pytest.mark.parametrize("width", [9, 8, 3])
+def test_shared_tangent_launch_equals_plain_launch_and_rejects_mixed_groups(width):
+    """LgarDims.tangent_share = W: the W direction-lanes of a column share the Geff trapezoid (W = 9: all 3 x L directions of a
+    three-layer column, seven groups and one idle lane per wavefront).  Values -- and so the status words -- are bit-identical to
+    the plain launch; the tangents are summed in another order: equal to rounding (median difference 0, 99.5 % of the entries
+    within 1e-9 of the largest gradient), except where the gradient itself is ill-conditioned: alpha h does not depend on alpha
+    (h = f(Se) / alpha), so the alpha direction's d(alpha h) is pure cancellation noise in BOTH launches (and in the reference's
+    autograd), which a near-saturated column multiplies by ~1e9: those entries (1-2 of 4500 here) agree to 1e-3 of their own
+    size, 1e-6 of the largest gradient -- the bar of the reference fixtures.  The wrapper refuses groups whose columns are not
+    one soil column."""
     import lgar_py_amd as lg
     from lgar_py_amd import workloads as W
-    N = 512
+    N = 500  # 500 x 9 = 4500 columns: ragged last wavefront
     E = W.ensemble_columns(N, seed=3)
     f = W.synth1_forcing()
     T = f.shape[0]
     pr = torch.tensor(f[:, 0:1], device="cuda")
     pe = torch.zeros_like(pr)
     w = torch.rand(T, 1, device="cuda", dtype=torch.float64)
-    rep = {k: np.repeat(v, 8, axis=1) for k, v in E.items()}
+    rep = {k: np.repeat(v, width, axis=1) for k, v in E.items()}
     eng = lg.LgarEngine(rep["alpha"], rep["n"], rep["ksat"], rep["theta_e"], rep["theta_r"], rep["thickness"],
                         dt_h=300.0 / 3600.0, ponded_depth_max=0.0, dtype=torch.float64, with_state=False)
-    dirs = {k: torch.zeros(3, 8 * N, dtype=torch.float64, device="cuda") for k in ("alpha", "n", "ksat")}
-    for b, (kind, l) in enumerate([("alpha", 0), ("alpha", 1), ("n", 0), ("n", 1), ("n", 2), ("ksat", 0), ("ksat", 1), ("ksat", 2)]):
-        dirs[kind][l, b::8] = 1.0
-    g0, _, s0 = eng.tangent(dirs, pr, pe, w_runoff=w, forcing_group=8)
-    g1, _, s1 = eng.tangent(dirs, pr, pe, w_runoff=w, forcing_group=8, share=8)
+    dirs = {k: torch.zeros(3, width * N, dtype=torch.float64, device="cuda") for k in ("alpha", "n", "ksat")}
+    basis = [(kind, l) for kind in ("alpha", "n", "ksat") for l in range(3)]
+    for b in range(width):
+        kind, l = basis[b % 9]
+        dirs[kind][l, b::width] = 1.0
+    g0, _, s0 = eng.tangent(dirs, pr, pe, w_runoff=w, forcing_group=width)
+    g1, _, s1 = eng.tangent(dirs, pr, pe, w_runoff=w, forcing_group=width, share=width)
     assert torch.equal(s0, s1)
     ok = (s0 & 0x7F) == 0
     scale = float(g0[ok].abs().max())
-    assert float((g0 - g1)[ok].abs().max()) <= 1e-9 * scale and scale > 0
+    d = (g0 - g1)[ok].abs()
+    assert scale > 0 and float(d.max()) <= 1e-6 * scale
+    assert float(d.median()) <= 1e-12 * scale and float((d > 1e-9 * scale).double().mean()) <= 5e-3
     mixed = rep["ksat"].copy()
-    mixed[0, 3] *= 1.01
+    mixed[0, 3 if width > 3 else 1] *= 1.01
     bad = lg.LgarEngine(rep["alpha"], rep["n"], mixed, rep["theta_e"], rep["theta_r"], rep["thickness"],
                         dt_h=300.0 / 3600.0, ponded_depth_max=0.0, dtype=torch.float64, with_state=False)
     with pytest.raises(lg.LgarError, match="identical soil parameters"):
-        bad.tangent(dirs, pr, pe, w_runoff=w, forcing_group=8, share=8)
+        bad.tangent(dirs, pr, pe, w_runoff=w, forcing_group=width, share=width)

@@ -13,7 +13,8 @@ cfg = config.load_config(cwd=tmp, overrides={"data.forcing_file": write_forcing(
                                              "data.soil_params_file": write_soil_dat(os.path.join(tmp, "data", "s.dat")), "models.endtime": float(n)})
 data = Data(cfg)
 model = dpLGAR(cfg); mb = MassBalance(cfg, model)
-with torch.no_grad():
+mode = sys.argv[1] if len(sys.argv) > 1 else "no_grad"
+with (torch.enable_grad() if mode == "grad" else torch.no_grad()):
     for i in range(20): model(data[i][0]); mb.change_mass(model)
     torch.cuda.synchronize()
     pr = cProfile.Profile(); pr.enable(); t0=time.perf_counter()
