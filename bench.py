@@ -557,8 +557,34 @@ def main():
             subs["configs1"] = {"value": 10_000 * Tc / (min(ms) * 1e-3), "unit": "column-timesteps/s", "kernel_ms": min(ms),
                                 "columns": 10_000, "timesteps": Tc, "dtype": "f64",
                                 "workload": "BASELINE configs[1]: 10k replicated Phillipsburg columns x 3000 hourly steps, fp64 "
-                                            "(157 waves on 1024 SIMDs: latency-bound, not a throughput figure)"}
+                                            "(157 waves on 1024 SIMDs: bound by the time ONE wave needs for 3000 steps, not a "
+                                            "throughput figure; 8 cooperating lanes would make it 1250 waves -- more than one per "
+                                            "SIMD -- and were measured slower, so this size runs one lane per column)"}
             del ec, pc, qc
+            # the reference's own use: ONE column (agents/DifferentiableLGAR.py:117-125), 3000 hourly rows in one launch, with
+            # one lane and with the library's choice of cooperating lanes (64 for a job this small; same results bit for bit)
+            one = {}
+            for label, lanes in (("one_lane", 1), ("cooperating_lanes", 0)):
+                g1 = np.load(os.path.join(ROOT, "tests", "golden", "phil_hourly_3000.npz"))
+                P1 = W.PHILLIPSBURG
+                e1 = lg.LgarEngine(*[P1[k] for k in ("alpha", "n", "ksat", "theta_e", "theta_r", "thickness")], n_columns=1,
+                                   dt_h=1.0, ponded_depth_max=2.0, dtype=torch.float64, device=dev, forward_lanes=lanes)
+                p1 = torch.tensor(g1["forcing"][:, 0:1], device=dev).contiguous()
+                q1 = torch.tensor(g1["forcing"][:, 1:2], device=dev).contiguous()
+                ms = []
+                for _ in range(3):
+                    e1.reset()
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record()
+                    e1.forward(p1, q1, series=("runoff", "percolation"), check=False)
+                    b.record()
+                    torch.cuda.synchronize()
+                    ms.append(a.elapsed_time(b))
+                one[label] = {"kernel_ms": min(ms), "column_timesteps_per_s": p1.shape[0] / (min(ms) * 1e-3)}
+            subs["single_column"] = dict(one, columns=1, timesteps=int(p1.shape[0]), dtype="f64",
+                                         workload="the bundled Phillipsburg column x 3000 hourly steps in one launch (the "
+                                                  "reference: 12.9 steps/s); jobs under one wave per SIMD give every column "
+                                                  "8..64 lanes that split the Geff trapezoid")
             # BASELINE configs[4]: 100 000-column vG parameter ensemble, forward + backward (autograd through the HIP
             # kernels: 9 parameter directions as one tangent launch), loss = mean of runoff^2
             from lgar_py_amd.autograd import lgar_series

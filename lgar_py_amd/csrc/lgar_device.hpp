@@ -610,10 +610,12 @@ __device__ __forceinline__ double geff_mixed(const LayerK<double> &l, double the
   }
   const float xcutf = (float)xcut;
   const float nf = (float)l.n, nf_lo = (float)(l.n - (double)nf), mmf = (float)(-l.m), mmf_lo = (float)(-l.m - (double)mmf);
-  const f32x2 n2 = {nf, nf}, nl2 = {nf_lo, nf_lo}, hm2 = {hm, hm}, hml2 = {hm_lo, hm_lo}, one2 = {1.0f, 1.0f}, two2 = {2.0f, 2.0f};
-  const f32x2 ln2_2 = {0.693147181f, 0.693147181f}, c2_2 = {0.5f, 0.5f}, c3_2 = {1.0f / 6.0f, 1.0f / 6.0f};
-  const f32x2 c4_2 = {1.0f / 24.0f, 1.0f / 24.0f}, c5_2 = {1.0f / 120.0f, 1.0f / 120.0f};
-  const f32x2 mm2 = {mmf, mmf}, mml2 = {mmf_lo, mmf_lo}, ilog2 = {1.44269504f, 1.44269504f};
+  const f32x2 n2 = {nf, nf}, nl2 = {nf_lo, nf_lo}, hm2 = {hm, hm}, hml2 = {hm_lo, hm_lo}, one2 = {1.0f, 1.0f};
+  // expm1(E ln 2) / E = ln 2 + E (ln^2 2 / 2 + E (ln^3 2 / 6 + E (ln^4 2 / 24 + E ln^5 2 / 120)))
+  const f32x2 ln2_2 = {0.693147181f, 0.693147181f}, c2_2 = {0.240226507f, 0.240226507f}, c3_2 = {0.0555041087f, 0.0555041087f};
+  const f32x2 c4_2 = {0.00961812911f, 0.00961812911f}, c5_2 = {0.00133335581f, 0.00133335581f};
+  const f32x2 mm2 = {mmf, mmf}, mml2 = {mmf_lo, mmf_lo}, ilog2 = {1.44269504f, 1.44269504f}, two_ilog2 = {2.88539008f, 2.88539008f};
+  const f32x2 half2 = {0.5f, 0.5f};
   // one node pair: sqrt(Se) and (1 - P Se)^2 of the nodes at X.x, X.y
 #define LGAR_GEFFM_PAIR(X, SR, TT)                                                          \
   {                                                                                         \
@@ -625,24 +627,23 @@ __device__ __forceinline__ double geff_mixed(const LayerK<double> &l, double the
     const f32x2 c = one2 + r;                                                               \
     const f32x2 rho = r - (c - one2);                                                       \
     Lc.x = lg2(c.x); Lc.y = lg2(c.y);                                                       \
-    f32x2 ic = two2 - c; /* ~ 1/c where the correction matters (c near 1); nothing for c >= 2 */ \
+    /* (2 - c) / ln 2 ~ 1 / (c ln 2) where the correction matters (c near 1); nothing for c >= 2 */ \
+    f32x2 ic = __builtin_elementwise_fma(-ilog2, c, two_ilog2);                             \
     ic.x = fmaxf(ic.x, 0.0f); ic.y = fmaxf(ic.y, 0.0f);                                     \
-    const f32x2 L = __builtin_elementwise_fma(rho * ic, ilog2, Lc);                         \
-    /* sqrt(Se) = (1 + a)^(-m/2) = 2^(-m/2 (log2 a + L)) */                                 \
-    const f32x2 l1 = la + L;                                                                \
-    const f32x2 e1 = __builtin_elementwise_fma(hm2, l1, hml2 * l1);                         \
-    (SR).x = ex2(e1.x); (SR).y = ex2(e1.y);                                                 \
-    /* t = 1 - (a/(1+a))^m = 1 - 2^E with E = -m L.  Dry nodes have 2^E -> 1: there t = -expm1(E ln 2) by its series  \
-       (5 terms for 2^E > 7/8), not by the cancelling difference */                         \
+    const f32x2 L = __builtin_elementwise_fma(rho, ic, Lc);                                 \
+    /* E = -m L = log2 (a/(1+a))^m;  sqrt(Se) = (1 + a)^(-m/2) = 2^(-m/2 (log2 a + L)) = 2^(-m/2 log2 a + E/2) */ \
     const f32x2 E = __builtin_elementwise_fma(mm2, L, mml2 * L);                            \
+    const f32x2 e1 = __builtin_elementwise_fma(hm2, la, __builtin_elementwise_fma(hml2, la, half2 * E)); \
+    (SR).x = ex2(e1.x); (SR).y = ex2(e1.y);                                                 \
+    /* t = 1 - 2^E.  Dry nodes have 2^E -> 1: there t = -expm1(E ln 2) by its series in E (5 terms for 2^E > 7/8), not by \
+       the cancelling difference */                                                         \
     f32x2 w;                                                                                \
     w.x = ex2(E.x); w.y = ex2(E.y);                                                         \
-    const f32x2 y = E * ln2_2;                                                              \
-    f32x2 p = __builtin_elementwise_fma(c5_2, y, c4_2);                                     \
-    p = __builtin_elementwise_fma(p, y, c3_2);                                              \
-    p = __builtin_elementwise_fma(p, y, c2_2);                                              \
-    p = __builtin_elementwise_fma(p, y, one2);                                              \
-    const f32x2 ts = -y * p;                                                                \
+    f32x2 p = __builtin_elementwise_fma(c5_2, E, c4_2);                                     \
+    p = __builtin_elementwise_fma(p, E, c3_2);                                              \
+    p = __builtin_elementwise_fma(p, E, c2_2);                                              \
+    p = __builtin_elementwise_fma(p, E, ln2_2);                                             \
+    const f32x2 ts = -E * p;                                                                \
     f32x2 t = one2 - w;                                                                     \
     t.x = (w.x > 0.875f) ? ts.x : t.x;                                                      \
     t.y = (w.y > 0.875f) ? ts.y : t.y;                                                      \
@@ -650,8 +651,8 @@ __device__ __forceinline__ double geff_mixed(const LayerK<double> &l, double the
   }
   double acc = 0.0, accb = 0.0;  // node pairs with even / odd index
   int it = 0;
-  for (; it + 1 < safe_pairs; it += 2) {  // four nodes per iteration: two independent chains
-    const double j0 = double(2 * it + 1);
+  double j0 = 1.0;  // index of the first node of the current pair, as a double (no integer -> double conversion per iteration)
+  for (; it + 1 < safe_pairs; it += 2, j0 += 4.0) {  // four nodes per iteration: two independent chains
     const f32x2 xa = {(float)fma(j0, dx, x0), (float)fma(j0 + 1.0, dx, x0)};
     const f32x2 xb = {(float)fma(j0 + 2.0, dx, x0), (float)fma(j0 + 3.0, dx, x0)};
     f32x2 sa, ta, sb, tb;
@@ -662,8 +663,7 @@ __device__ __forceinline__ double geff_mixed(const LayerK<double> &l, double the
     const f32x2 kb = sb * tb;
     accb = accb + (double)(kb.x + kb.y);
   }
-  for (; it < pairs; it++) {  // the odd safe pair and the nodes that may fall under the |h| < 0.1 cut: K_r = ksat1 there
-    const double j0 = double(2 * it + 1);
+  for (; it < pairs; it++, j0 += 2.0) {  // the odd safe pair and the nodes that may fall under the |h| < 0.1 cut: K_r = ksat1 there
     const f32x2 x = {(float)fma(j0, dx, x0), (float)fma(j0 + 1.0, dx, x0)};
     f32x2 sr, tt;
     LGAR_GEFFM_PAIR(x, sr, tt)
