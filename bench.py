@@ -512,16 +512,21 @@ def main():
                 # (profiles/*/isa_census.txt: 2 log2 + 2 exp2 by polynomial, no hardware transcendental), all of them at the
                 # v_fma_f64 issue rate except two v_rcp_f64 at a quarter of it (profiles/r02/valu_probe_f64_helpers.jsonl)
                 calls64 = e64.geff_wave_calls() / 3.0
-                node_insts, node_issue_slots = 93, 93 + 2 * 3
-                if probe.get("v_fma_f64"):
-                    subs["fp64"]["valu_roofline"] = {
-                        "bound": "valu-issue", "unit": "wave-instructions/s", "peak_v_fma_f64": probe["v_fma_f64"],
-                        "geff_wave_calls_per_launch": calls64, "vector_instructions_per_trapezoid_node": node_insts,
-                        "achieved_geff_instructions": calls64 * 121 * node_insts / (ms * 1e-3),
-                        "frac_of_fma64_issue_peak": calls64 * 121 * node_issue_slots / (ms * 1e-3) / probe["v_fma_f64"],
-                        "note": "the trapezoid's fp64 instruction stream (in v_fma_f64 issue slots) per second of the WHOLE kernel "
-                                "time over the chip's measured v_fma_f64 issue rate: the rest of the kernel time is the column "
-                                "physics outside the trapezoid and lanes idled by divergence"}
+                # one node = 93 vector instructions (profiles/*/isa_census.txt), all issuing like v_fma_f64 except two v_rcp_f64
+                # at a quarter of that rate (profiles/r02/valu_probe_f64_helpers.jsonl): 99 issue slots.  Peak: the chip's fp64
+                # vector rate, 78.6 TFLOP/s (AMD's MI355X specification; = one 64-lane v_fma_f64 per 4 cycles per SIMD at the
+                # 2.4 GHz of MI355X_MICROARCH.md) = 6.14e11 wave-instructions/s (128 flop each); the live probe
+                # of v_fma_f64 is reported next to it (its own loop reaches ~75 % of that: a lower bound, not the roof).
+                peak64 = 78.6e12 / 128.0
+                slots = calls64 * 121 * 99
+                subs["fp64"]["valu_roofline"] = {
+                    "bound": "valu-issue", "unit": "wave-instructions/s", "peak_v_fma_f64": peak64,
+                    "probe_v_fma_f64": probe.get("v_fma_f64"), "geff_wave_calls_per_launch": calls64,
+                    "vector_instructions_per_trapezoid_node": 93, "issue_slots_per_trapezoid_node": 99,
+                    "achieved_geff_issue_slots": slots / (ms * 1e-3), "frac_of_issue_peak": slots / (ms * 1e-3) / peak64,
+                    "note": "the trapezoid's fp64 instruction stream, in v_fma_f64 issue slots per second of the WHOLE kernel time, "
+                            "over the chip's fp64 vector issue rate: the rest of the kernel time is the column physics outside "
+                            "the trapezoid and lanes idled by divergence"}
                 del e64, p64, q64
                 # fp64 column state with the fp32 hardware transcendentals inside the Geff trapezoid (LgarDims.geff_mode = 1):
                 # run totals of every column within 2e-6 of the native fp64 kernels', identical fault flags (tests/test_gpu_mixed.py)

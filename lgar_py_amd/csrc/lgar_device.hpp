@@ -99,6 +99,8 @@ __device__ __forceinline__ double mn(double a, double b) { return fmin(a, b); }
 __device__ __forceinline__ float mn(float a, float b) { return fminf(a, b); }
 __device__ __forceinline__ bool is_nan(double x) { return x != x; }
 __device__ __forceinline__ bool is_nan(float x) { return x != x; }
+__device__ __forceinline__ bool same_bits(double a, double b) { return a == b; }  // (NaN never matches: recomputed)
+__device__ __forceinline__ bool same_bits(float a, float b) { return a == b; }
 
 // Measurement points (cost attribution, tools/ablate.py): LGAR_MEASURE_POINT(NAME, args) marks a place where a measurement
 // build can run a routine twice or count something, LGAR_ABLATABLE(NAME, statement) a statement such a build can leave out.
@@ -787,6 +789,9 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
   // new_front_frozen marks a front created in the current sub-step, whose K carries frozen_factor (Layer.py:1410-1412).
   S k_deepest;
   bool new_front_frozen;
+  // insert_water's Geff of the last call and what it was computed from (see insert_water): layer -1 = nothing remembered
+  S memo_theta, memo_g;
+  int memo_layer = -1;
   bool count_geff = false;              // measurement: count wave-level Geff evaluations in the unused upper bits of `status`
   int share_lanes = 0;                  // tangent kernels: W = 2..32 adjacent lanes carry this same column (other directions);
                                         // forward kernels: 2..64 = that many adjacent lanes carry this very column (small jobs)
@@ -1455,7 +1460,19 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
     // quirk: with a fully saturated one-front top layer right after a layer crossing, nxt_i is a front of the
     // NEXT layer and Se > 1: the reference raises ValueError (negative pow base, physics/utils.py:25-27);
     // here the NaN is flagged and the IEEE min below drops it (all ponded water infiltrates).
-    if (nf != NL) g = capillary_drive(lk, F.TH(nxt_i < nf ? nxt_i : nf - 1), lk.te, 3);
+    // Geff(theta_1 -> theta_e) is a pure function of theta_1 and the layer's parameters, and during a storm theta_1 -- the
+    // front BEHIND the wetting front, usually the layer's untouched boundary front -- stays the same for many steps: the
+    // value of the previous call is reused when its inputs are bit for bit the same (the whole trapezoid is skipped when
+    // that holds for every column of the wavefront; same results either way).
+    if (nf != NL) {
+      const S theta_1 = F.TH(nxt_i < nf ? nxt_i : nf - 1);
+      if (memo_layer == kfp && same_bits(theta_1, memo_theta)) {
+        g = memo_g;
+      } else {
+        g = capillary_drive(lk, theta_1, lk.te, 3);
+        memo_theta = theta_1; memo_g = g; memo_layer = kfp;
+      }
+    }
     if (is_nan(val(g))) status |= LGAR_ST_NAN | LGAR_ST_NEGBASE;
     S f_p;
     if (kfp == 0) {

@@ -20,6 +20,7 @@ template <typename R> struct Dual {
 template <typename R> struct Real<Dual<R>> { using type = R; };
 
 template <typename R> __device__ __forceinline__ R val(const Dual<R> &x) { return x.v; }
+template <typename R> __device__ __forceinline__ bool same_bits(const Dual<R> &a, const Dual<R> &b) { return a.v == b.v && a.d == b.d; }
 template <typename R> __device__ __forceinline__ Dual<R> choose(bool c, const Dual<R> &a, const Dual<R> &b) {
   return Dual<R>(c ? a.v : b.v, c ? a.d : b.d);
 }

@@ -49,7 +49,12 @@ static void launch_one(TArgs<R> &a, unsigned nblocks, unsigned *ticket, hipStrea
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
       cus = 256;
-    const unsigned slots = (unsigned)cus * 4u;  // one wave per SIMD: the dual-number kernels hold 256 VGPRs + ~130 AGPRs
+    // resident one-wave workgroups per CU for THIS kernel (registers and LDS decide: 4 for the fp64 dual-number kernels --
+    // 256 VGPRs + ~180 AGPRs, one wave per SIMD -- 8 for the fp32 ones)
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lgar_tangent_kernel<R, NL, CAP, MODE>, WAVE, 0) != hipSuccess || per_cu <= 0)
+      per_cu = 4;
+    const unsigned slots = (unsigned)cus * (unsigned)per_cu;
     grid = nblocks < slots ? nblocks : slots;
   }
   hipLaunchKernelGGL((lgar_tangent_kernel<R, NL, CAP, MODE>), dim3(grid), dim3(WAVE), 0, st, a);
