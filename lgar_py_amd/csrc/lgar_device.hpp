@@ -718,14 +718,28 @@ template <typename S, int POL = 0> __device__ __forceinline__ S geff_closed(cons
   return g;
 }
 
-// calc_aet, models/physics/lgar/aet.py:17-51 (0.75: GlobalParams.py:75; clamp upper bound = PET rate)
-template <typename S, int POL = 0> __device__ __forceinline__ S aet_fn(const LayerK<S> &l, S pet, real_t<S> dt_h, S psi, real_t<S> wp_psi) {
+// calc_aet, models/physics/lgar/aet.py:17-51 (0.75: GlobalParams.py:75; clamp upper bound = PET rate).  The head at which
+// uptake halves (aet.py:31-40) depends on the top layer's parameters only: aet_psi_wp computes it, the column keeps it.
+template <typename S, int POL = 0> __device__ __forceinline__ S aet_psi_wp(const LayerK<S> &l, real_t<S> wp_psi) {
   using R = real_t<S>;
   S theta_fc = (l.te - l.tr) * R(0.75) + l.tr;
   S wp_head_theta = theta_from_h<S, POL>(l, S(wp_psi));
   S theta_wp = (theta_fc - wp_head_theta) * R(0.5) + wp_head_theta;
   S se = se_from_theta(l, theta_wp);
-  S psi_wp = h_from_se<S, POL>(l, se);
+  return h_from_se<S, POL>(l, se);
+}
+template <typename S, int POL = 0> __device__ __forceinline__ S aet_from_psi_wp(S pet, real_t<S> dt_h, S psi, S psi_wp) {
+  using R = real_t<S>;
+  S r = psi / psi_wp;
+  S h_ratio = R(1.0) + r * r * r;
+  S a = pet * (R(1.0) / h_ratio) * dt_h;
+  if (val(a) < R(0.0)) a = S(R(0.0));
+  if (val(a) > val(pet)) a = pet;
+  return a;
+}
+template <typename S, int POL = 0> __device__ __forceinline__ S aet_fn(const LayerK<S> &l, S pet, real_t<S> dt_h, S psi, real_t<S> wp_psi) {
+  using R = real_t<S>;
+  S psi_wp = aet_psi_wp<S, POL>(l, wp_psi);
   S r = psi / psi_wp;
   S h_ratio = R(1.0) + r * r * r;
   S a = pet * (R(1.0) / h_ratio) * dt_h;
@@ -792,6 +806,8 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
   // insert_water's Geff of the last call and what it was computed from (see insert_water): layer -1 = nothing remembered
   S memo_theta, memo_g;
   int memo_layer = -1;
+  S aet_psi_wp_memo;          // calc_aet's half-uptake head of this column (a function of the top layer's parameters only)
+  bool aet_psi_wp_known = false;
   bool count_geff = false;              // measurement: count wave-level Geff evaluations in the unused upper bits of `status`
   int share_lanes = 0;                  // tangent kernels: W = 2..32 adjacent lanes carry this same column (other directions);
                                         // forward kernels: 2..64 = that many adjacent lanes carry this very column (small jobs)
@@ -1557,7 +1573,13 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
       LGAR_MEASURE_POINT(DUP_FDD)
       const int fdd = free_drainage_front();
       const bool saturated = val(F.TH(0)) >= val(P.te[0]);  // Layer.is_saturated, Layer.py:785-793
-      if (val(pet) > R(0.0)) AET_sub = aet_fn<S, POL>(pick_static(P, 0), pet, dt, F.PS(0), G->wp_psi);
+      if (val(pet) > R(0.0)) {
+        if (!aet_psi_wp_known) {  // four pows, once per column and launch instead of once per sub-step
+          aet_psi_wp_memo = aet_psi_wp<S, POL>(pick_static(P, 0), G->wp_psi);
+          aet_psi_wp_known = true;
+        }
+        AET_sub = aet_from_psi_wp<S, POL>(pet, dt, F.PS(0), aet_psi_wp_memo);
+      }
       a_precip = a_precip + precip_sub;
       a_pet = a_pet + ((val(pet_sub) > R(0.0)) ? pet_sub : S(R(0.0)));
       // Single call site for the front move (models/dpLGAR.py:199-266 re-ordered, same data flow): columns
