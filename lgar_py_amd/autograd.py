@@ -185,9 +185,11 @@ class StepTape:
 
     def reset(self):
         self.x = []          # forcing chunks [Tc, N, 2] since the last set_internal_states()
+        self.n_rows = 0      # ... and how many forcing rows they hold
         self.w = {}          # (chunk, 0|1) -> gradient received, [Tc, N]
         self.token = None
         self.versions = None
+        self._params = None  # the model's parameters in (alpha, n, ksat) x layer order, looked up once per recorded series
 
     def _param_lists(self):
         m = self._model()
@@ -198,8 +200,11 @@ class StepTape:
     def record(self, x_chunk, runoff_chunk, perc_chunk, steps_before=None):
         """x_chunk [Tc, N, 2]; runoff/perc [Tc, N] (engine outputs); steps_before: forcing rows the model had integrated
         since set_internal_states() before this chunk.  Returns the graph-connected blocks."""
-        m, plists = self._param_lists()
-        recorded = sum(int(xc.shape[0]) for xc in self.x)
+        if self._params is None:
+            _, plists = self._param_lists()
+            self._params = [p for _, pl in plists for p in pl]
+        params = self._params
+        recorded = self.n_rows
         if steps_before is not None and steps_before != recorded:
             # finalize() re-integrates the tangent from a FRESH state over the recorded rows only: rows the model advanced
             # off the tape (under torch.no_grad(), or while no parameter required grad -- a spin-up, say) would make the
@@ -207,7 +212,6 @@ class StepTape:
             raise LgarError("the model advanced %d forcing rows since set_internal_states() that are not on the autograd tape "
                             "(%d recorded): forward() calls under torch.no_grad() cannot be mixed with differentiated ones "
                             "within one series; call set_internal_states() first" % (steps_before - recorded, recorded))
-        params = [p for _, pl in plists for p in pl]
         versions = tuple(p._version for p in params)
         if self.versions is None:
             self.versions = versions
@@ -216,6 +220,7 @@ class StepTape:
                             "before backward): call set_internal_states() first, the gradient would belong to another run")
         ci = len(self.x)
         self.x.append(x_chunk.detach())
+        self.n_rows += int(x_chunk.shape[0])
         token = self.token if self.token is not None else torch.zeros((), dtype=torch.float64)
         r, p, self.token = _ChunkFunction.apply(self, ci, token, runoff_chunk, perc_chunk, *params)
         return r, p

@@ -42,6 +42,17 @@ class GlobalParams:
 
 
 class dpLGAR(nn.Module):
+    # plain-tensor attributes the agent loop rewrites ~20 times per forcing row (forward() and MassBalance.change_mass):
+    # stored without nn.Module's parameter / buffer / submodule bookkeeping (2.5 us per assignment, a third of a row's host time)
+    _PLAIN = frozenset(("precip", "PET", "AET", "infiltration", "runoff", "giuh_runoff", "discharge", "groundwater_discharge",
+                        "percolation", "previous_precip", "_latest", "steps_advanced"))
+
+    def __setattr__(self, name, value):
+        if name in dpLGAR._PLAIN:
+            object.__setattr__(self, name, value)
+        else:
+            super().__setattr__(name, value)
+
     def __init__(self, cfg, n_columns=None, theta_e=None, theta_r=None, alpha=None, n=None, ksat=None):
         """cfg: the reference's config keys (see config.py).  Optional per-column overrides ([N, L] tensors) turn the
         single column into an ensemble; otherwise every column gets the table values of cfg.data.layer_soil_type."""
