@@ -79,3 +79,40 @@ def test_two_rank_sharding_matches_single_process():
         assert np.allclose(r[4], basin1.numpy(), rtol=1e-12, atol=1e-12)  # same reduced runoff up to summation order
         assert np.array_equal(r[5], np.full(3, 3.0))           # 1 + 2: gradient all-reduce
     assert basin1.sum() > 0
+
+
+def _force_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lgar_py_amd import distributed as D
+    calls = []
+    real = D._all_reduce
+    D._all_reduce = lambda t, group=None: (calls.append(1), real(t, group))[1]
+    s = torch.arange(12, dtype=torch.float64).reshape(4, 3)
+    os.environ.pop("LGAR_FORCE_DIST", None)
+    a = D.basin_runoff(s)
+    n_plain = len(calls)
+    os.environ["LGAR_FORCE_DIST"] = "1"
+    b = D.basin_runoff(s)
+    q.put((n_plain, len(calls), a.numpy(), b.numpy()))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_force_dist_runs_the_collective_in_a_group_of_one():
+    """LGAR_FORCE_DIST=1: the basin all-reduce executes even when the group has one member (how a one-GPU box exercises the RCCL
+    path, tests/test_gpu_distributed.py); without it a group of one skips the exchange.  Same result either way."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_force_worker, args=(0, 1, port, q))
+    p.start()
+    n_plain, n_total, a, b = q.get(timeout=100)
+    p.join(30)
+    assert n_plain == 0 and n_total == 1 and np.array_equal(a, b) and np.array_equal(a, np.arange(12.0).reshape(4, 3).sum(1))

@@ -33,9 +33,13 @@ for seed in range(SEEDS):
         ro, pc, acc, st = O.run_columns(P["alpha"], P["n"], P["ksat"], P["theta_e"], P["theta_r"], P["thickness"], pr, pe,
                                         pdm=kw["pdm"], dt_h=kw["dt_h"])
         t_or = time.time() - t0
-        for mode in (1, 0, 2):
+        for mode in (1, 0, 2, "mixed"):
+            # "mixed": search mode 1 with the mixed-precision trapezoid (geff_precision="f32"): identical fault flags required,
+            # run totals within 2e-6 of the column's water input, per-step runoff within 2e-4 of the largest;
+            # the wide-parameter shape is reported only (there 0.2 % of the columns change their fault flag in the mixed mode)
+            mk = dict(search_mode=1, geff_precision="f32") if mode == "mixed" else dict(search_mode=mode)
             eng = lg.LgarEngine(P["alpha"], P["n"], P["ksat"], P["theta_e"], P["theta_r"], P["thickness"], dt_h=kw["dt_h"],
-                                ponded_depth_max=kw["pdm"], dtype=torch.float64, search_mode=mode)
+                                ponded_depth_max=kw["pdm"], dtype=torch.float64, **mk)
             out = eng.forward(torch.tensor(pr), torch.tensor(pe), series=("runoff", "percolation"), check=False)
             gst = eng.status.cpu().numpy() & 0x7f
             both = (st == 0) & (gst == 0)
@@ -48,17 +52,23 @@ for seed in range(SEEDS):
             tot = eng.totals.cpu().numpy()
             e_tot = float((np.abs(tot[:8] - acc[:8]) / np.maximum(np.abs(acc[:8]), 1e-3))[:, both].max())
             e_vol = float((np.abs(tot[9] - acc[9]) / np.maximum(np.abs(acc[9]), 1e-6))[both].max())
+            if mode == "mixed":  # totals against the column's water input
+                e_tot = float((np.abs(tot[:8] - acc[:8]) / np.maximum(np.maximum(np.abs(acc[:8]), acc[0:1]), 1e-2))[:, both].max())
             col_err = np.abs(got_ro - ro).max(0) / max(1.0, np.abs(ro).max())
             n_div = int((col_err[both] > 1e-6).sum())
             rec = dict(seed=seed, shape=shape, mode=mode, columns=int(pr.shape[1]), steps=int(pr.shape[0]), valid=float(both.mean()),
                        flag_mismatches=n_flag_diff, columns_off_by_more_than_1e_6=n_div, err_runoff=e_ro, err_perc=e_pc,
                        err_totals=e_tot, err_volume=e_vol, oracle_s=round(t_or, 1))
             print(json.dumps(rec), flush=True)
-            worst = max(worst, e_ro, e_pc, e_tot, e_vol)
             # The wide ensemble (n up to 3, Ksat over 2.5 decades) saturates its top layers, where psi -> 0 and the
             # reference's own decisions (isclose ties at 1e-8, the Se > 1 fault of insert_water) are decided by the last
             # ulp of pow: a few columns in 10^4 take the other branch under ANY other libm or search order.  Reported,
             # not failed; the +-10 % shapes must agree exactly.
+            if mode == "mixed":
+                if shape != "wide" and (n_flag_diff or e_tot > 2e-6 or e_vol > 2e-6 or max(e_ro, e_pc) > 2e-4):
+                    fail = True
+                continue
+            worst = max(worst, e_ro, e_pc, e_tot, e_vol)
             if shape != "wide" and (n_flag_diff or max(e_ro, e_pc, e_tot, e_vol) > 1e-6):
                 fail = True
             if shape == "wide" and (n_flag_diff + n_div) > 1e-3 * pr.shape[1]:
@@ -100,11 +110,12 @@ for name in (FIXTURES if os.environ.get("SWEEP_FIXTURES", "1") != "0" else []):
             ss = O.init_state(pp)
             r = O.run(pp, ss, pr[:, c], pe[:, c], fronts=False)
             ro[:, c] = r["acc"][:, 4]; acc[:, c] = r["acc"].sum(0); acc[9, c] = r["acc"][-1, 9]; st[c] = r["status"]
-    for mode in (1, 0, 2):
+    for mode in ((1, 0, 2) if closed else (1, 0, 2, "mixed")):
+        mk = dict(search_mode=1, geff_precision="f32") if mode == "mixed" else dict(search_mode=mode)
         eng = lg.LgarEngine(P["alpha"], P["n"], P["ksat"], P["theta_e"], P["theta_r"], P["thickness"], dt_h=kw["dt_h"],
                             num_subcycles=kw["num_subcycles"], ponded_depth_max=kw["pdm"], initial_psi=kw["initial_psi"],
                             wilting_point_psi=kw["wp_psi"], frozen_factor=kw["frozen_factor"], nint=kw["nint"],
-                            giuh_ordinates=kw["giuh"], use_closed_form_G=closed, dtype=torch.float64, search_mode=mode)
+                            giuh_ordinates=kw["giuh"], use_closed_form_G=closed, dtype=torch.float64, **mk)
         out = eng.forward(torch.tensor(pr), torch.tensor(pe), series=("runoff",), check=False)
         gst = eng.status.cpu().numpy() & 0x7f
         both = (st == 0) & (gst == 0)
@@ -113,11 +124,18 @@ for name in (FIXTURES if os.environ.get("SWEEP_FIXTURES", "1") != "0" else []):
         col_err = np.abs(got - ro).max(0) / max(1.0, np.abs(ro).max())
         tot = eng.totals.cpu().numpy()
         e_tot = float((np.abs(tot[2:6] - acc[2:6]) / np.maximum(np.abs(acc[2:6]), 1e-3))[:, both].max()) if both.any() else 0.0
+        if mode == "mixed" and both.any():
+            e_tot = float((np.abs(tot[2:6] - acc[2:6]) / np.maximum(np.maximum(np.abs(acc[2:6]), acc[0:1]), 1e-2))[:, both].max())
         e_ro = float(col_err[both].max()) if both.any() else 0.0
         rec = dict(fixture=name, layers=L, mode=mode, columns=n, steps=T, valid=float(both.mean()), flag_mismatches=n_flag_diff,
                    columns_off_by_more_than_1e_6=int((col_err[both] > 1e-6).sum()), err_runoff=e_ro, err_totals=e_tot,
                    max_fronts=int(eng.n_fronts.max()))
         print(json.dumps(rec), flush=True)
+        if mode == "mixed":
+            if n_flag_diff or e_tot > 5e-6 or e_ro > 2e-4:  # (observed: 2.4e-6 on the perturbed two_layer_synth1 family, else <= 8e-7)
+                fail = True
+                print("  mixed mode outside its bars", flush=True)
+            continue
         worst = max(worst, e_ro, e_tot)
         if n_flag_diff or max(e_ro, e_tot) > 1e-6:
             fail = True
