@@ -282,45 +282,60 @@ __device__ __forceinline__ void geff_shared_blocks(const LayerK<S> &l, const S &
 }
 #ifndef LGAR_DEVSIM
 // The trapezoid's interior for COOPERATING lanes (forward kernels on jobs too small to fill the chip, LgarDims.forward_lanes):
-// the `lanes` lanes of an aligned group all carry the SAME column -- same values, same branches -- so node j is evaluated by
-// lane j mod lanes only, left in the wave's LDS buffer, and every lane then adds the nodes up in order.  Heads, node values
-// and the sum are those of the plain loop bit for bit: each node goes through the same operations on the same operands
-// (h2 by the same repeated addition), only once per group instead of once per lane.
+// the `lanes` lanes of an aligned group all carry the SAME column -- same values, same branches.  `tab` is the group's table
+// of LGAR_COOP_TAB doubles in LDS.
+//   1. every lane runs the plain loop's running sum h2 += dh and leaves head j in tab[j] (the lanes of a group store the same
+//      value to the same address);
+//   2. lane r evaluates nodes r, r + lanes, r + 2 lanes, ... -- two at a time, as the plain loop does -- and puts K(head) where
+//      the head was (no other lane reads that head);
+//   3. every lane adds the nodes up in order.
+// Heads, node values and the sum are those of the plain loop bit for bit: each node goes through the same operations on the
+// same operands, only once per group instead of once per lane.
+#define LGAR_COOP_TAB 128      /* most trapezoid intervals a cooperating job may have (LgarDims.nint; 120 in every bundled config) */
+#define LGAR_COOP_TAB_ROW 130  /* doubles per group's table in LDS: padded so that the groups' tables start on different banks */
 __device__ __forceinline__ void geff_nodes_cooperative(const LayerK<double> &l, double nm1, double half_m, double k_sat1, double &h2,
-                                                       double dh, double hdh, double &g, double &k1, int nint, int lanes, double *xchg) {
-  const int lane = (int)(threadIdx.x & 63u);
-  const int r = lane & (lanes - 1);
-  double *grp = xchg + (lane & ~(lanes - 1));
-  for (int i0 = 0; i0 < nint; i0 += lanes) {
-    const int cnt = (nint - i0 < lanes) ? nint - i0 : lanes;
-    // the heads of this round by the running sum of the plain loop; mine is number r
-    double hm = h2;
-    for (int q = 0; q < cnt; q++) {
-      hm = (q == r) ? h2 : hm;
-      h2 = h2 + dh;
-    }
-    double k2 = geff_node(l, nm1, half_m, hm);
-    k2 = (fabs(hm) < 0.1 || hm < 0.0) ? k_sat1 : k2;  // utils.py:124-128 (never true on the nodes the plain loop leaves unchecked)
-    // one wave = one workgroup: LDS operations of a wave complete in order, the fences only pin the compiler
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    grp[r] = k2;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    // (eight LDS reads in flight at a time: one wave alone on its SIMD has nothing else to cover their latency)
-    for (int q0 = 0; q0 < cnt; q0 += 8) {
-      double kq[8];
-#pragma unroll
-      for (int j = 0; j < 8; j++) kq[j] = grp[(q0 + j < cnt) ? q0 + j : cnt - 1];  // same address in every lane of the group: a broadcast
-#pragma unroll
-      for (int j = 0; j < 8; j++)
-        if (q0 + j < cnt) {
-          g = g + ((k1 + kq[j]) * hdh);
-          k1 = kq[j];
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // the next round's stores stay behind these loads
-    __builtin_amdgcn_wave_barrier();
+                                                       double dh, double hdh, double &g, double &k1, int nint, int lanes, double *tab) {
+  const int r = (int)(threadIdx.x & 63u) & (lanes - 1);
+  // one wave = one workgroup: LDS operations of a wave complete in order, the fences only pin the compiler
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // (earlier loads of the table stay in front of these stores)
+  for (int j = 0; j < nint; j++) {
+    tab[j] = h2;  // (the lanes of a group store the same value to the same address; predicating the store on one lane was
+    h2 = h2 + dh; //  measured SLOWER: 72 -> 92 ms for one column)
   }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  for (int ja = r; ja < nint; ja += 2 * lanes) {
+    const int jb = ja + lanes;
+    const bool two = jb < nint;
+    const double ha = tab[ja], hb = tab[two ? jb : ja];
+    double ka = geff_node(l, nm1, half_m, ha);
+    double kb = geff_node(l, nm1, half_m, hb);
+    ka = (fabs(ha) < 0.1 || ha < 0.0) ? k_sat1 : ka;  // utils.py:124-128 (never true on the nodes the plain loop leaves unchecked)
+    kb = (fabs(hb) < 0.1 || hb < 0.0) ? k_sat1 : kb;
+    tab[ja] = ka;
+    if (two) tab[jb] = kb;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  // (eight LDS reads in flight at a time: one wave alone on its SIMD has nothing else to cover their latency)
+  int q0 = 0;
+  for (; q0 + 8 <= nint; q0 += 8) {
+    double kq[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) kq[j] = tab[q0 + j];  // same address in every lane of the group: a broadcast
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      g = g + ((k1 + kq[j]) * hdh);
+      k1 = kq[j];
+    }
+  }
+  for (; q0 < nint; q0++) {
+    const double kq = tab[q0];
+    g = g + ((k1 + kq) * hdh);
+    k1 = kq;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // the next call's stores stay behind these loads
+  __builtin_amdgcn_wave_barrier();
 }
 #endif
 #ifndef LGAR_DEVSIM
@@ -341,8 +356,8 @@ __device__ __forceinline__ void geff_ends_cooperative(const LayerK<double> &l, d
   const double op = pw(base, is_h ? l.inv_n : l.m);
   const double t = 1.0 - op;
   const double mine = is_h ? (1.0 / l.alpha) * op : l.ksat * sqrt(se) * (t * t);
-  double *grp = xchg + (lane & ~(lanes - 1));
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  double *grp = xchg;  // the group's table
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   if ((lane & (lanes - 1)) < 4) grp[which] = mine;  // lanes 0..3 of the group (lanes >= 4)
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   __builtin_amdgcn_wave_barrier();
@@ -380,33 +395,38 @@ __device__ __forceinline__ S geff_fused(const LayerK<S> &l, S theta1, S theta2, 
   S h2 = h_i + dh;
   // four transcendentals per node: P = a^m = x^(n-1), a = x P, sqrt(Se) = (1+a)^(-m/2), (a/(1+a))^m = P Se
   auto node = [&](const S &h) { return geff_node(l, nm1, half_m, h); };
-  // The |h| < 0.1 -> Se = 1 rule (utils.py:124-128) can only bind on a SUFFIX of the nodes (h falls monotonically from
-  // h_i to h_f): a wave-uniform count of leading nodes that no lane needs to test runs select-free.
-  const R jf = (val(h_i) - R(0.1)) / -val(dh) - R(2.0);
-  int safe = (jf > R(0.0)) ? ((jf < R(nint)) ? int(jf) : nint) : 0;  // NaN (dh == 0) -> 0
-  int n_safe = nint;
-  if (any_lane(safe < nint) != 0ull) {
-    n_safe = 0;
-    for (int bit = 128; bit; bit >>= 1) {
-      const int cand = n_safe + bit;
-      if (cand <= nint && any_lane(safe < cand) == 0ull) n_safe = cand;
+  int i = 0;
+#ifndef LGAR_DEVSIM
+  bool nodes_done = false;
+  if constexpr (sizeof(S) == 8 && sizeof(R) == 8) {
+    if (coop > 1 && xchg != nullptr) {  // cooperating lanes: every node is checked against the |h| < 0.1 rule by its evaluator
+      geff_nodes_cooperative(l, nm1, half_m, k_sat1, h2, dh, hdh, g, k1, nint, coop, xchg);
+      nodes_done = true;
     }
   }
-  int i = 0;
+  if (nodes_done) i = nint;
+#endif
+  // The |h| < 0.1 -> Se = 1 rule (utils.py:124-128) can only bind on a SUFFIX of the nodes (h falls monotonically from
+  // h_i to h_f): a wave-uniform count of leading nodes that no lane needs to test runs select-free.
+  int n_safe = nint;
+  if (i < nint) {
+    const R jf = (val(h_i) - R(0.1)) / -val(dh) - R(2.0);
+    const int safe = (jf > R(0.0)) ? ((jf < R(nint)) ? int(jf) : nint) : 0;  // NaN (dh == 0) -> 0
+    if (any_lane(safe < nint) != 0ull) {
+      n_safe = 0;
+      for (int bit = 128; bit; bit >>= 1) {
+        const int cand = n_safe + bit;
+        if (cand <= nint && any_lane(safe < cand) == 0ull) n_safe = cand;
+      }
+    }
+  }
   if constexpr (sizeof(S) != sizeof(R) && sizeof(R) == 8) {
     if (xchg != nullptr && coop >= 2 && n_safe >= coop) {  // coop: the W lanes that share this column (LgarDims.tangent_share)
       geff_shared_blocks(l, nm1, half_m, h2, dh, hdh, g, k1, n_safe / coop, coop, xchg);
       i = (n_safe / coop) * coop;
     }
   }
-#ifndef LGAR_DEVSIM
-  if constexpr (sizeof(S) == 8 && sizeof(R) == 8) {
-    if (coop > 1 && xchg != nullptr) {
-      geff_nodes_cooperative(l, nm1, half_m, k_sat1, h2, dh, hdh, g, k1, nint, coop, xchg);
-      i = nint;
-    }
-  }
-#endif
+
   // fp64 and its dual numbers: two nodes per iteration give the scheduler two independent chains (same sums in the same
   // order; measured: backward -1.5 %, fp64 forward -1 %, a job of 157 waves -3 %)
   if constexpr (sizeof(R) == 8) {
@@ -760,21 +780,26 @@ template <typename R> struct Glob {
 
 // LDS view of one lane's fronts: element i of field f sits at base[(f * FMAX + i) * WAVE] (one base address per lane; the
 // field offsets are compile-time constants folded into the ds_read / ds_write offsets)
-template <typename S, int FMAX> struct FrontsView {
-  S *base;             // &lds.f[0][0][lane]
-  unsigned char *fl;   // &lds.fl[0][lane]
-  __device__ __forceinline__ S &Z(int i) const { return base[(0 * FMAX + i) * WAVE]; }
-  __device__ __forceinline__ S &TH(int i) const { return base[(1 * FMAX + i) * WAVE]; }
-  __device__ __forceinline__ S &PS(int i) const { return base[(2 * FMAX + i) * WAVE]; }
-  __device__ __forceinline__ S &DZ(int i) const { return base[(3 * FMAX + i) * WAVE]; }
-  __device__ __forceinline__ int layer(int i) const { return fl[i * WAVE] & 0x7f; }
-  __device__ __forceinline__ bool bottom(int i) const { return (fl[i * WAVE] & LGAR_FLAG_BOTTOM) != 0; }
+// STRIDE: table slots per front row -- 64, one per lane; the cooperating-lanes kernels (MODE 4) keep ONE table per group of
+// lanes (LGAR_COOP_GROUPS slots: the lanes of a group hold the same column, read the same address -- an LDS broadcast -- and
+// write the same value to it), which is what lets a 32-front table of such a wave fit four waves per CU.
+#define LGAR_COOP_GROUPS 16
+template <typename S, int FMAX, int STRIDE = WAVE> struct FrontsView {
+  S *base;             // &lds.f[0][0][slot]
+  unsigned char *fl;   // &lds.fl[0][slot]
+  __device__ __forceinline__ S &Z(int i) const { return base[(0 * FMAX + i) * STRIDE]; }
+  __device__ __forceinline__ S &TH(int i) const { return base[(1 * FMAX + i) * STRIDE]; }
+  __device__ __forceinline__ S &PS(int i) const { return base[(2 * FMAX + i) * STRIDE]; }
+  __device__ __forceinline__ S &DZ(int i) const { return base[(3 * FMAX + i) * STRIDE]; }
+  __device__ __forceinline__ unsigned char &flag(int i) const { return fl[i * STRIDE]; }
+  __device__ __forceinline__ int layer(int i) const { return fl[i * STRIDE] & 0x7f; }
+  __device__ __forceinline__ bool bottom(int i) const { return (fl[i * STRIDE] & LGAR_FLAG_BOTTOM) != 0; }
   __device__ __forceinline__ void set_flag(int i, int layer, bool bottom) const {
-    fl[i * WAVE] = (unsigned char)(layer | (bottom ? LGAR_FLAG_BOTTOM : 0));
+    fl[i * STRIDE] = (unsigned char)(layer | (bottom ? LGAR_FLAG_BOTTOM : 0));
   }
   __device__ __forceinline__ void copy(int dst, int src) const {
     Z(dst) = Z(src); TH(dst) = TH(src); PS(dst) = PS(src); DZ(dst) = DZ(src);
-    fl[dst * WAVE] = fl[src * WAVE];
+    fl[dst * STRIDE] = fl[src * STRIDE];
   }
 };
 
@@ -785,14 +810,16 @@ template <typename S, int FMAX> struct FrontsView {
 // MODE 1 (default of the engine, what bench.py measures): the same roots by bracketed Newton / closed-form jumps; the
 // passes that are provably no-ops between events are skipped (see forward()).
 // MODE 3 (double precision only, LgarDims.geff_mode = 1): MODE 1 with the mixed-precision trapezoid (geff_mixed).
+// MODE 4 (double precision only, jobs under one wave per SIMD): MODE 1 with cooperating lanes (geff_*_cooperative).
 template <typename S, int NL, int FMAX, int MODE> struct Column {
   using R = real_t<S>;
   // arithmetic policy (see dv / pwx): verification mode in double precision uses the library pow (the reference's
   // torch.pow); the plain-float fast mode divides by reciprocal; everything else is lean pow + IEEE division
   static constexpr int POL = ((MODE == 0) && (sizeof(R) == 8)) ? 1 : (((MODE != 0) && (sizeof(S) == 4)) ? 2 : 0);
+  static constexpr int STRIDE = (MODE == 4) ? LGAR_COOP_GROUPS : WAVE;  // front-table slots per row (see FrontsView)
   const ColParams<S, NL> &P;
   const LGAR_KARG Glob<R> *G;  // run-time constants, in the kernarg segment (re-pointed by the kernel's time loop)
-  FrontsView<S, FMAX> F;
+  FrontsView<S, FMAX, STRIDE> F;
   int nf;
   int status;
   S ponded_water, previous_precip, ending_volume;
@@ -816,7 +843,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
   // accumulators drained every forcing step (physics/MassBalance.py:45-53)
   S a_precip, a_pet, a_aet, a_infil, a_runoff, a_perc, a_giuh, a_disch;
 
-  __device__ Column(const ColParams<S, NL> &p, const LGAR_KARG Glob<R> *g, const FrontsView<S, FMAX> &f) : P(p), G(g), F(f) {}
+  __device__ Column(const ColParams<S, NL> &p, const LGAR_KARG Glob<R> *g, const FrontsView<S, FMAX, STRIDE> &f) : P(p), G(g), F(f) {}
 
   __device__ __forceinline__ S cum_at(int k) const { return sel<S, NL>(P.cum, k); }
   // calc_geff (lgar/green_ampt.py:19-99): trapezoid or closed form, per cfg.data.use_closed_form_G
@@ -832,7 +859,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
     if constexpr (sizeof(S) != sizeof(R) && sizeof(R) == 8 && MODE != 0) {
       if (share_lanes >= 2 && !G->closed_form) return geff_fused<S>(lk, theta1, theta2, G->nint, xchg, share_lanes);
     }
-    if constexpr (MODE == 1 && sizeof(S) == 8 && sizeof(R) == 8) {  // plain double: cooperating lanes (small jobs)
+    if constexpr (MODE == 4 && sizeof(S) == 8 && sizeof(R) == 8) {  // plain double: cooperating lanes (small jobs)
       if (share_lanes > 1 && !G->closed_form) return geff_fused<S>(lk, theta1, theta2, G->nint, xchg, share_lanes);
     }
     if constexpr (MODE == 3 && sizeof(S) == 8 && sizeof(R) == 8) {  // plain double, LgarDims.geff_mode = 1
@@ -1343,10 +1370,10 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
   __device__ __forceinline__ bool front_event_pending() const {
     bool ev = false;
     S z1 = F.Z(0), t1 = F.TH(0);
-    int f1 = F.fl[0];
+    int f1 = F.flag(0);
     for (int i = 0; i + 1 < nf; i++) {
       const S z2 = F.Z(i + 1), t2 = F.TH(i + 1);
-      const int f2 = F.fl[(i + 1) * WAVE];
+      const int f2 = F.flag(i + 1);
       const bool same = ((f1 ^ f2) & 0x7f) == 0;
       ev = ev || (same && !(f2 & LGAR_FLAG_BOTTOM) && val(z1) > val(z2));   // passing
       ev = ev || (same && val(t1) <= val(t2));                                // dry over wet

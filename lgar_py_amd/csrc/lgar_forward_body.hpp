@@ -54,11 +54,13 @@ template <int SR> __device__ __forceinline__ constexpr int sum_row(int j) {
   return (SR >= 8) ? (j < 8 ? j : -1) : ((j < 5) ? (j < SR ? j : -1) : ((j == 6 && SR >= 6) ? 5 : -1));
 }
 
-template <typename S, int FMAX, int SUMROWS = LdsSums<S, FMAX>::rows> struct WaveLDS {
-  S f[4][FMAX][WAVE];
-  unsigned char fl[FMAX][WAVE];
+template <typename S, int FMAX, int SUMROWS = LdsSums<S, FMAX>::rows, int STRIDE = WAVE> struct WaveLDS {
+  S f[4][FMAX][STRIDE];
+  unsigned char fl[FMAX][STRIDE];
   S sums[SUMROWS][WAVE];
 };
+// the wave's LDS block of a forward kernel: one front table per lane, or (MODE 4) per group of cooperating lanes
+template <typename R, int FMAX, int MODE> using ForwardLDS = WaveLDS<R, FMAX, LdsSums<R, FMAX>::rows, (MODE == 4) ? LGAR_COOP_GROUPS : WAVE>;
 
 #ifndef LGAR_DEVSIM
 __device__ __forceinline__ double wave_sum(double v) {
@@ -107,10 +109,11 @@ __device__ __forceinline__ void load_params(const LGAR_KARG KArgs<R> &a, size_t 
   }
 }
 
-template <typename S, int FMAX> __device__ __forceinline__ FrontsView<S, FMAX> make_view(S *f, unsigned char *fl, int lane) {
-  FrontsView<S, FMAX> F;
-  F.base = f + lane;
-  F.fl = fl + lane;
+template <typename S, int FMAX, int STRIDE = WAVE>
+__device__ __forceinline__ FrontsView<S, FMAX, STRIDE> make_view(S *f, unsigned char *fl, int slot) {
+  FrontsView<S, FMAX, STRIDE> F;
+  F.base = f + slot;
+  F.fl = fl + slot;
   return F;
 }
 
@@ -127,7 +130,7 @@ __device__ __forceinline__ void store_state(const LGAR_KARG KArgs<R> &a, size_t 
     a.psi[i * N + c] = live ? col.F.PS(i) : R(0);
     a.k[i * N + c] = live ? ((i < col.nf - 1) ? col.front_k(i, pick(col.P, col.F.layer(i))) : col.k_deepest) : R(0);
     a.dzdt[i * N + c] = live ? col.F.DZ(i) : R(0);
-    a.flags[i * N + c] = live ? col.F.fl[i * WAVE] : (uint8_t)0;
+    a.flags[i * N + c] = live ? col.F.flag(i) : (uint8_t)0;
   }
   a.nf[c] = col.nf;
   a.scalars[0 * N + c] = col.ponded_water;
@@ -161,7 +164,7 @@ __device__ __forceinline__ void init_lane(const LGAR_KARG KArgs<R> *ap, size_t c
 // wave's exchange buffer); `leader` is true for the one lane of the group that stores the column's results.
 template <typename R, int NL, int FMAX, int MODE>
 __device__ __forceinline__ void forward_lane(const LGAR_KARG KArgs<R> *ap, size_t c, bool live, int lane,
-                                             WaveLDS<R, FMAX> &lds, bool leader = true, R *xchg = nullptr) {
+                                             ForwardLDS<R, FMAX, MODE> &lds, bool leader = true, R *xchg = nullptr) {
   const LGAR_KARG KArgs<R> &a = *ap;
   const size_t N = (size_t)a.N;
   const bool basin_on = (a.basin != nullptr) && (a.basin_mask != 0u);
@@ -178,7 +181,10 @@ __device__ __forceinline__ void forward_lane(const LGAR_KARG KArgs<R> *ap, size_
   status &= LGAR_ST_FAULT_MASK;
   ColParams<R, NL> P;
   load_params<R, NL>(a, c, P);
-  Column<R, NL, FMAX, MODE> col(P, &ap->G, make_view<R, FMAX>(&lds.f[0][0][0], &lds.fl[0][0], lane));
+  // front-table slot: my own, or (MODE 4) my group's -- the lanes of a group hold the same column
+  constexpr int STRIDE = Column<R, NL, FMAX, MODE>::STRIDE;
+  const int slot = (MODE == 4) ? lane / (a.coop > 0 ? a.coop : 1) : lane;
+  Column<R, NL, FMAX, MODE> col(P, &ap->G, make_view<R, FMAX, STRIDE>(&lds.f[0][0][0], &lds.fl[0][0], slot));
   // state HBM -> LDS / registers
   const int nf_stored = a.nf[c];
   const int cap = FMAX < a.F ? FMAX : a.F;
@@ -190,7 +196,7 @@ __device__ __forceinline__ void forward_lane(const LGAR_KARG KArgs<R> *ap, size_
     col.F.TH(i) = a.theta[i * N + c];
     col.F.PS(i) = a.psi[i * N + c];
     col.F.DZ(i) = a.dzdt[i * N + c];
-    col.F.fl[i * WAVE] = a.flags[i * N + c];
+    col.F.flag(i) = a.flags[i * N + c];
   }
   col.ponded_water = a.scalars[0 * N + c];
   col.previous_precip = a.scalars[1 * N + c];

@@ -42,7 +42,8 @@ inline int check_dims(const LgarDims *d) {
   if (d->forcing_columns > 0 && (d->n_columns / forcing_group(d)) % d->forcing_columns != 0) return LGAR_E_ARG;
   if (d->tangent_share != 0 && (d->tangent_share < 2 || d->tangent_share > 32 || d->n_columns % d->tangent_share != 0)) return LGAR_E_ARG;
   if (d->geff_mode < 0 || d->geff_mode > 1) return LGAR_E_ARG;
-  if (d->forward_lanes < 0 || d->forward_lanes > 64 || (d->forward_lanes & (d->forward_lanes - 1)) != 0) return LGAR_E_ARG;
+  if (d->forward_lanes < 0 || d->forward_lanes > 64 || (d->forward_lanes & (d->forward_lanes - 1)) != 0 || d->forward_lanes == 2)
+    return LGAR_E_ARG;
   if (!(d->dt_h > 0.0)) return LGAR_E_ARG;
   return 0;
 }

@@ -42,16 +42,17 @@ __global__ __launch_bounds__(WAVE) void lgar_init_kernel(KArgs<R> a) {
   init_lane<R, NL, CAP>((const LGAR_KARG KArgs<R> *)__builtin_amdgcn_kernarg_segment_ptr(), c, lane, lds);
 }
 
-// LDS buffer through which cooperating lanes exchange trapezoid nodes (lgar_device.hpp geff_nodes_cooperative): only the
-// double-precision fast kernels have the mode; 8 front slots + sums + this = exactly 20 KiB per wave (8 waves per CU)
+// LDS tables through which cooperating lanes exchange trapezoid heads and nodes (lgar_device.hpp geff_nodes_cooperative): one
+// per group of lanes, MODE 4 kernels only (double precision).  With the front table kept once per group as well, a 32-front
+// wave of such a kernel takes 37 KB: four waves per CU, one per SIMD -- all a cooperating job may have.
 template <typename R, int MODE> struct CoopLDS {
-  static constexpr bool on = (sizeof(R) == 8) && (MODE == 1);
-  R v[on ? WAVE : 1];
+  static constexpr bool on = (sizeof(R) == 8) && (MODE == 4);
+  R tab[on ? LGAR_COOP_GROUPS : 1][on ? LGAR_COOP_TAB_ROW : 1];
 };
 
 template <typename R, int NL, int CAP, int MODE>
 __global__ __launch_bounds__(WAVE, (Occupancy<R, CAP>::waves)) void lgar_forward_kernel(KArgs<R> a) {
-  __shared__ WaveLDS<R, CAP> lds;
+  __shared__ ForwardLDS<R, CAP, MODE> lds;
   __shared__ CoopLDS<R, MODE> coop_lds;
   const int lane = threadIdx.x;
   // the argument block is read in place (kernarg segment), see LGAR_KARG in lgar_device.hpp
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(WAVE, (Occupancy<R, CAP>::waves)) void lgar_forward
       if (coop > 1) {
         const size_t c0 = ((size_t)blk * WAVE + lane) / (size_t)coop;
         const bool live = c0 < N;
-        forward_lane<R, NL, CAP, MODE>(ap, live ? c0 : N - 1, live, lane, lds, (lane & (coop - 1)) == 0, &coop_lds.v[0]);
+        forward_lane<R, NL, CAP, MODE>(ap, live ? c0 : N - 1, live, lane, lds, (lane & (coop - 1)) == 0, &coop_lds.tab[lane / coop][0]);
         continue;
       }
     }
@@ -164,6 +165,10 @@ static void launch_fast_kernel(KArgs<R> &a, unsigned nblocks, unsigned *ticket, 
       launch_forward_kernel<R, NL, CAP, 3>(a, nblocks, ticket, st);
       return;
     }
+    if (a.coop > 1) {  // cooperating lanes: the 32-front kernel, whose LDS is per group of lanes (forward_typed)
+      if constexpr (CAP == LGAR_FMAX) launch_forward_kernel<R, NL, CAP, 4>(a, nblocks, ticket, st);
+      return;
+    }
   }
   (void)mixed;
   launch_forward_kernel<R, NL, CAP, 1>(a, nblocks, ticket, st);
@@ -171,15 +176,17 @@ static void launch_fast_kernel(KArgs<R> &a, unsigned nblocks, unsigned *ticket, 
 
 // lanes per column for this job: LgarDims.forward_lanes when given, else the largest power of two <= 64 that keeps the job
 // within ONE wave per SIMD (n_columns * lanes / 64 <= simds) -- two such waves on a SIMD contend for its vector ALU in the
-// trapezoid and the gain is gone (measured: 10 000 columns x 8 lanes = 1250 waves run slower than 157 plain ones).  Fewer
-// than 8 lanes do not pay for the exchange (measured), so the answer is 1, 8, 16, 32 or 64; always 1 for fp32, closed-form G,
-// the literal mode and the mixed-precision trapezoid.
+// trapezoid and the gain is gone (measured: 10 000 columns x 8 lanes = 1250 waves run slower than 157 plain ones).  The
+// answer is 1, 4, 8, 16, 32 or 64 (the groups' LDS tables exist for at most 16 groups per wave: not 2); always 1 for fp32,
+// closed-form G, the literal mode, the mixed-precision trapezoid and more than 128 trapezoid intervals.
 template <typename R> static int cooperating_lanes(const LgarDims *dims, unsigned simds) {
   if (sizeof(R) != 8 || dims->search_mode == 0 || dims->use_closed_form_G || dims->geff_mode != 0) return 1;
+  if (dims->nint > LGAR_COOP_TAB) return 1;  // the groups' LDS tables hold one head / node per trapezoid interval
   if (dims->forward_lanes > 0) return dims->forward_lanes;
+  if (dims->search_mode == 2) return 1;      // the capacity chain was asked for (tests): plain kernels
   int lanes = 1;
   while (lanes < WAVE && ((size_t)dims->n_columns * (size_t)(lanes * 2) + WAVE - 1) / WAVE <= (size_t)simds) lanes *= 2;
-  return lanes >= 8 ? lanes : 1;
+  return lanes >= 4 ? lanes : 1;
 }
 
 // The front-capacity chain of one lgar_forward call (see lgar_forward_body.hpp).
@@ -202,14 +209,13 @@ static int forward_typed(const LgarDims *dims, const LgarParams *params, LgarSta
   // Jobs that cannot fill the chip (the reference's own use is ONE column, agents/DifferentiableLGAR.py:117-125): in double
   // precision every column gets 8..64 cooperating lanes that split the Geff trapezoid's nodes and the pows that open it
   // (lgar_device.hpp geff_nodes_cooperative / geff_ends_cooperative).  Results are bit for bit those of one lane per column.
-  // Such a job starts with the 16-slot kernel: one wave per SIMD is all it has, and the 8-slot kernel would only add a
-  // hand-over (the bundled Phillipsburg column reaches 8 fronts).
+  // Such a job runs the 32-front kernel directly (MODE 4: front table and exchange table once per GROUP of lanes, 37 KB of LDS
+  // per wave, one wave per SIMD): no capacity chain, no hand-over.
   a.coop = cooperating_lanes<R>(dims, wave_slots(1));
-  const bool tiny = grid <= 1024u && dims->search_mode != 2 && a.coop == 1;  // search_mode 2: chain forced (tests)
+  const bool tiny = (grid <= 1024u && dims->search_mode != 2) || a.coop > 1;  // search_mode 2: chain forced (tests)
   int caps[3], nc = 0;
-  const int first_cap = (a.coop > 1 && dims->search_mode != 2) ? LGAR_CAP_MID : LGAR_CAP_SMALL;
-  if (!tiny && need <= LGAR_CAP_SMALL && slots > LGAR_CAP_SMALL && first_cap <= LGAR_CAP_SMALL) caps[nc++] = LGAR_CAP_SMALL;
-  if (!tiny && need <= LGAR_CAP_MID && slots > LGAR_CAP_MID && first_cap <= LGAR_CAP_MID) caps[nc++] = LGAR_CAP_MID;
+  if (!tiny && need <= LGAR_CAP_SMALL && slots > LGAR_CAP_SMALL) caps[nc++] = LGAR_CAP_SMALL;
+  if (!tiny && need <= LGAR_CAP_MID && slots > LGAR_CAP_MID) caps[nc++] = LGAR_CAP_MID;
   caps[nc++] = LGAR_FMAX;
   for (int i = 0; i < nc; i++) {
     a.chain_first = (i == 0);

@@ -503,13 +503,13 @@ def test_single_step_transitions_from_injected_reference_states(name):
         assert (res["layer"][:n, c] == g["front_layer"][k, :n]).all() and (res["to_bottom"][:n, c] == g["front_bottom"][k, :n]).all()
 
 
-@pytest.mark.parametrize("lanes", [8, 64])
+@pytest.mark.parametrize("lanes", [4, 8, 64])
 @pytest.mark.parametrize("name", ["phil_hourly_3000", "synth1_phil", "manyfronts_pulse_84", "five_layer_phil_500",
                                   "two_layer_synth1", "six_layer_synth1", "frozen07_phil_hourly_400"])
 def test_cooperating_lanes_reproduce_one_lane_per_column(name, lanes):
-    """LgarDims.forward_lanes: small fp64 jobs give every column 8..64 lanes that split the Geff trapezoid's nodes (and the
-    pows that open it) between them.  Every per-step output and the final front tables are those of one lane per column BIT
-    FOR BIT; run totals, which are summed per kernel of the capacity chain, to 1e-13."""
+    """LgarDims.forward_lanes: small fp64 jobs give every column 4..64 lanes that split the Geff trapezoid's nodes (and the
+    pows that open it) between them, with one front table per group of lanes.  Every per-step output, the final front tables
+    and the run totals are those of one lane per column BIT FOR BIT."""
     import lgar_py_amd as lg
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     ncol = 5
@@ -525,11 +525,11 @@ def test_cooperating_lanes_reproduce_one_lane_per_column(name, lanes):
         assert torch.equal(a[nm], b[nm]), nm
     for t in ("depth", "theta", "psi", "k", "dzdt", "flags", "n_fronts", "status", "scalars"):
         assert torch.equal(getattr(ea, t), getattr(eb, t)), t
-    assert torch.allclose(ea.totals, eb.totals, rtol=1e-13, atol=1e-13)
+    assert torch.equal(ea.totals, eb.totals)
 
 
 def test_cooperating_lanes_on_distinct_columns_and_the_default_choice():
-    """200 different columns: the library's own choice (16 lanes for this size) and a forced 8 reproduce one lane per column."""
+    """200 different columns: the library's own choice (64 lanes for this size) and a forced 8 reproduce one lane per column."""
     import lgar_py_amd as lg
     from lgar_py_amd import workloads as W
     N = 200
