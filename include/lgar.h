@@ -114,7 +114,7 @@ typedef struct {
   int32_t forward_lanes;     /* lgar_forward, LGAR_F64 fast modes with the trapezoid (ignored elsewhere).  0: the library decides --
                                 jobs under one wave per SIMD get 4..64 cooperating lanes per column, which split the nodes of
                                 the Geff trapezoid between them (results bit for bit those of one lane per column); 1: one lane
-                                per column whatever the job size; 4, 8, .. 64: that many */
+                                per column whatever the job size; 4 .. 64: that many (64 / lanes columns per wavefront) */
   int32_t reserved4;
 } LgarDims;
 
@@ -175,6 +175,10 @@ typedef struct {
 const char *lgar_version(void);
 int32_t lgar_fmax(void);
 int32_t lgar_lmax(void);
+/* Lanes per column lgar_forward would use for these dims and dtype (LgarDims.forward_lanes = 0: the library's choice for jobs
+ * under one wave per SIMD; 1 = every column its own lane).  A pure function of its arguments and of the device's CU count
+ * (256 when no device is visible). */
+int32_t lgar_cooperating_lanes(const LgarDims *dims, int32_t dtype);
 
 /* dpLGAR.set_internal_states() (models/dpLGAR.py:97-147): one to_bottom front per layer at
  * psi = initial_psi, theta = theta(initial_psi); zero scalars/totals; status = 0. */

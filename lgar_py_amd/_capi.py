@@ -21,7 +21,7 @@ ACC_NAMES = ["precip", "PET", "AET", "infiltration", "runoff", "percolation", "g
 ST_NAN, ST_NEGBASE, ST_THETA_ORDER, ST_OVERFLOW, ST_ITERCAP, ST_BOTTOM, ST_STRUCT = 1, 2, 4, 8, 16, 32, 64
 STATUS_NAMES = {1: "NaN", 2: "negative pow base", 4: "theta order", 8: "front overflow", 16: "iteration cap",
                 32: "front reached domain bottom", 64: "structural error"}
-EXPORTS = ["lgar_version", "lgar_fmax", "lgar_lmax", "lgar_state_init", "lgar_forward", "lgar_forward_tangent",
+EXPORTS = ["lgar_version", "lgar_fmax", "lgar_lmax", "lgar_cooperating_lanes", "lgar_state_init", "lgar_forward", "lgar_forward_tangent",
            "lgar_leaf_batch", "lgar_valu_probe", "lgar_valu_probe_insts"]
 
 
@@ -84,6 +84,8 @@ def load():
     lib.lgar_version.restype = C.c_char_p
     lib.lgar_fmax.restype = i32
     lib.lgar_lmax.restype = i32
+    lib.lgar_cooperating_lanes.restype = i32
+    lib.lgar_cooperating_lanes.argtypes = [p(LgarDims), i32]
     lib.lgar_state_init.restype = i32
     lib.lgar_state_init.argtypes = [p(LgarDims), p(LgarParams), p(LgarState), vp, i32, vp]
     lib.lgar_forward.restype = i32

@@ -293,9 +293,11 @@ __device__ __forceinline__ void geff_shared_blocks(const LayerK<S> &l, const S &
 // same operands, only once per group instead of once per lane.
 #define LGAR_COOP_TAB 128      /* most trapezoid intervals a cooperating job may have (LgarDims.nint; 120 in every bundled config) */
 #define LGAR_COOP_TAB_ROW 130  /* doubles per group's table in LDS: padded so that the groups' tables start on different banks */
+// (r: my place in the group.  The last group of a wavefront also takes the lanes left over when `lanes` does not divide 64:
+// their r >= lanes; they evaluate no node -- a node's table slot must be read as a head and rewritten by ONE lane -- and take
+// part in everything else.)
 __device__ __forceinline__ void geff_nodes_cooperative(const LayerK<double> &l, double nm1, double half_m, double k_sat1, double &h2,
-                                                       double dh, double hdh, double &g, double &k1, int nint, int lanes, double *tab) {
-  const int r = (int)(threadIdx.x & 63u) & (lanes - 1);
+                                                       double dh, double hdh, double &g, double &k1, int nint, int lanes, double *tab, int r) {
   // one wave = one workgroup: LDS operations of a wave complete in order, the fences only pin the compiler
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // (earlier loads of the table stay in front of these stores)
   for (int j = 0; j < nint; j++) {
@@ -304,7 +306,7 @@ __device__ __forceinline__ void geff_nodes_cooperative(const LayerK<double> &l, 
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   __builtin_amdgcn_wave_barrier();
-  for (int ja = r; ja < nint; ja += 2 * lanes) {
+  for (int ja = (r < lanes) ? r : nint; ja < nint; ja += 2 * lanes) {
     const int jb = ja + lanes;
     const bool two = jb < nint;
     const double ha = tab[ja], hb = tab[two ? jb : ja];
@@ -345,9 +347,8 @@ __device__ __forceinline__ void geff_nodes_cooperative(const LayerK<double> &l, 
 // finish, every value going through exactly the operations h_from_se / k_from_se apply to it (bit-identical results; the
 // serial chain of eight pows becomes one of two).
 __device__ __forceinline__ void geff_ends_cooperative(const LayerK<double> &l, double se_i, double se_f, double &h_i, double &h_f,
-                                                      double &k_i, double &k_sat1, int lanes, double *xchg) {
-  const int lane = (int)(threadIdx.x & 63u);
-  const int which = lane & 3;  // 0: h(Se_i), 1: h(Se_f), 2: K(Se_i), 3: K(1)
+                                                      double &k_i, double &k_sat1, double *xchg, int r) {
+  const int which = r & 3;  // 0: h(Se_i), 1: h(Se_f), 2: K(Se_i), 3: K(1)
   const bool is_h = which < 2;
   const double se = (which == 1) ? se_f : ((which == 3) ? 1.0 : se_i);
   const double sp = pw(se, is_h ? -l.inv_m : l.inv_m);
@@ -358,7 +359,7 @@ __device__ __forceinline__ void geff_ends_cooperative(const LayerK<double> &l, d
   const double mine = is_h ? (1.0 / l.alpha) * op : l.ksat * sqrt(se) * (t * t);
   double *grp = xchg;  // the group's table
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-  if ((lane & (lanes - 1)) < 4) grp[which] = mine;  // lanes 0..3 of the group (lanes >= 4)
+  if (r < 4) grp[which] = mine;  // lanes 0..3 of the group (a group has at least 4)
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   __builtin_amdgcn_wave_barrier();
   h_i = grp[0]; h_f = grp[1]; k_i = grp[2]; k_sat1 = grp[3];
@@ -367,7 +368,8 @@ __device__ __forceinline__ void geff_ends_cooperative(const LayerK<double> &l, d
 }
 #endif
 template <typename S>
-__device__ __forceinline__ S geff_fused(const LayerK<S> &l, S theta1, S theta2, int nint, real_t<S> *xchg = nullptr, int coop = 0) {
+__device__ __forceinline__ S geff_fused(const LayerK<S> &l, S theta1, S theta2, int nint, real_t<S> *xchg = nullptr, int coop = 0,
+                                        int rank = 0) {
   using R = real_t<S>;
   const S se_i = se_from_theta(l, theta1);
   const S se_f = se_from_theta(l, theta2);
@@ -376,7 +378,7 @@ __device__ __forceinline__ S geff_fused(const LayerK<S> &l, S theta1, S theta2, 
 #ifndef LGAR_DEVSIM
   if constexpr (sizeof(S) == 8 && sizeof(R) == 8) {
     if (coop >= 4 && xchg != nullptr) {
-      geff_ends_cooperative(l, se_i, se_f, h_i, h_f, k1, k_sat1, coop, xchg);
+      geff_ends_cooperative(l, se_i, se_f, h_i, h_f, k1, k_sat1, xchg, rank);
       ends_done = true;
     }
   }
@@ -400,7 +402,7 @@ __device__ __forceinline__ S geff_fused(const LayerK<S> &l, S theta1, S theta2, 
   bool nodes_done = false;
   if constexpr (sizeof(S) == 8 && sizeof(R) == 8) {
     if (coop > 1 && xchg != nullptr) {  // cooperating lanes: every node is checked against the |h| < 0.1 rule by its evaluator
-      geff_nodes_cooperative(l, nm1, half_m, k_sat1, h2, dh, hdh, g, k1, nint, coop, xchg);
+      geff_nodes_cooperative(l, nm1, half_m, k_sat1, h2, dh, hdh, g, k1, nint, coop, xchg, rank);
       nodes_done = true;
     }
   }
@@ -839,6 +841,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
   int share_lanes = 0;                  // tangent kernels: W = 2..32 adjacent lanes carry this same column (other directions);
                                         // forward kernels: 2..64 = that many adjacent lanes carry this very column (small jobs)
   R *xchg = nullptr;                    // ... and the wave's LDS buffer they exchange trapezoid nodes through
+  int coop_rank = 0;                    // forward kernels: my place in my group of cooperating lanes
   int cap = FMAX;                       // fronts this column may hold: min(kernel capacity, rows of the state arrays)
   // accumulators drained every forcing step (physics/MassBalance.py:45-53)
   S a_precip, a_pet, a_aet, a_infil, a_runoff, a_perc, a_giuh, a_disch;
@@ -860,7 +863,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
       if (share_lanes >= 2 && !G->closed_form) return geff_fused<S>(lk, theta1, theta2, G->nint, xchg, share_lanes);
     }
     if constexpr (MODE == 4 && sizeof(S) == 8 && sizeof(R) == 8) {  // plain double: cooperating lanes (small jobs)
-      if (share_lanes > 1 && !G->closed_form) return geff_fused<S>(lk, theta1, theta2, G->nint, xchg, share_lanes);
+      if (share_lanes > 1 && !G->closed_form) return geff_fused<S>(lk, theta1, theta2, G->nint, xchg, share_lanes, coop_rank);
     }
     if constexpr (MODE == 3 && sizeof(S) == 8 && sizeof(R) == 8) {  // plain double, LgarDims.geff_mode = 1
       if (!G->closed_form) return geff_mixed(lk, theta1, theta2, G->nint);

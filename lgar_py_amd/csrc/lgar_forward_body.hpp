@@ -18,7 +18,7 @@ namespace lgar {
 template <typename R> struct KArgs {
   int N, T, F;                                            // columns, forcing steps, rows of the per-front state arrays
   int Nf, Fg;                                             // forcing columns and group: column c reads forcing column (c / Fg) % Nf
-  int coop;                                               // lanes per column (1, or 2..64: cooperating lanes, small jobs)
+  int coop;                                               // lanes per column (1, or 4..64: cooperating lanes, small jobs)
   unsigned *ticket;                                       // null, or the work counter of this launch (persistent waves)
   int chain_first, chain_last;                            // position in the capacity chain (see above)
   const unsigned *pending_in;                             // null, or how many columns the previous kernel of the chain handed over
@@ -159,12 +159,13 @@ __device__ __forceinline__ void init_lane(const LGAR_KARG KArgs<R> *ap, size_t c
 // T x (dpLGAR.forward + MassBalance.change_mass) for one column; the time loop is inside.
 // `live` = false for the padding lanes of a ragged tail wave: they integrate a copy of the last column (all 64 lanes stay
 // active for the wave reductions) and store nothing.
-// Cooperating lanes (a.coop = 2..64, jobs too small to fill the chip): that many adjacent lanes integrate the SAME column c
+// Cooperating lanes (a.coop = 4..64, jobs too small to fill the chip): that many adjacent lanes integrate the SAME column c
 // redundantly -- same loads, same values, same branches -- and split the nodes of the Geff trapezoid between them (xchg: the
 // wave's exchange buffer); `leader` is true for the one lane of the group that stores the column's results.
 template <typename R, int NL, int FMAX, int MODE>
 __device__ __forceinline__ void forward_lane(const LGAR_KARG KArgs<R> *ap, size_t c, bool live, int lane,
-                                             ForwardLDS<R, FMAX, MODE> &lds, bool leader = true, R *xchg = nullptr) {
+                                             ForwardLDS<R, FMAX, MODE> &lds, bool leader = true, R *xchg = nullptr, int group = 0,
+                                             int rank = 0) {
   const LGAR_KARG KArgs<R> &a = *ap;
   const size_t N = (size_t)a.N;
   const bool basin_on = (a.basin != nullptr) && (a.basin_mask != 0u);
@@ -183,7 +184,7 @@ __device__ __forceinline__ void forward_lane(const LGAR_KARG KArgs<R> *ap, size_
   load_params<R, NL>(a, c, P);
   // front-table slot: my own, or (MODE 4) my group's -- the lanes of a group hold the same column
   constexpr int STRIDE = Column<R, NL, FMAX, MODE>::STRIDE;
-  const int slot = (MODE == 4) ? lane / (a.coop > 0 ? a.coop : 1) : lane;
+  const int slot = (MODE == 4) ? group : lane;
   Column<R, NL, FMAX, MODE> col(P, &ap->G, make_view<R, FMAX, STRIDE>(&lds.f[0][0][0], &lds.fl[0][0], slot));
   // state HBM -> LDS / registers
   const int nf_stored = a.nf[c];
@@ -211,6 +212,7 @@ __device__ __forceinline__ void forward_lane(const LGAR_KARG KArgs<R> *ap, size_
   col.count_geff = a.counters != nullptr;
   col.share_lanes = (xchg != nullptr) ? a.coop : 0;
   col.xchg = xchg;
+  col.coop_rank = rank;
   col.drain();
   // accumulators summed over the steps this kernel integrates: the first SR in LDS, the rest in registers
   constexpr int SR = LdsSums<R, FMAX>::rows;

@@ -42,11 +42,38 @@ inline int check_dims(const LgarDims *d) {
   if (d->forcing_columns > 0 && (d->n_columns / forcing_group(d)) % d->forcing_columns != 0) return LGAR_E_ARG;
   if (d->tangent_share != 0 && (d->tangent_share < 2 || d->tangent_share > 32 || d->n_columns % d->tangent_share != 0)) return LGAR_E_ARG;
   if (d->geff_mode < 0 || d->geff_mode > 1) return LGAR_E_ARG;
-  if (d->forward_lanes < 0 || d->forward_lanes > 64 || (d->forward_lanes & (d->forward_lanes - 1)) != 0 || d->forward_lanes == 2)
-    return LGAR_E_ARG;
+  if (d->forward_lanes < 0 || d->forward_lanes > 64 || d->forward_lanes == 2 || d->forward_lanes == 3) return LGAR_E_ARG;
   if (!(d->dt_h > 0.0)) return LGAR_E_ARG;
   return 0;
 }
+
+// wave slots of the chip for a kernel compiled for `waves` waves per SIMD
+inline unsigned wave_slots(int waves) {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    cus = n;
+  }
+  return (unsigned)cus * 4u * (unsigned)waves;
+}
+
+
+// lanes per column for this job: LgarDims.forward_lanes when given, else as many as keep the job within ONE wave per SIMD
+// (ceil(n_columns / 1024) columns per wavefront, 64 / that lanes each) -- two such waves on a SIMD contend for its vector ALU
+// in the trapezoid and the gain is gone (measured: 10 000 columns x 8 lanes = 1250 waves run slower than 157 plain ones; 6
+// lanes = 1000 waves).  At most 16 columns per wavefront (that many LDS tables): 4..64 lanes; always 1 for fp32, closed-form
+// G, the literal mode, the mixed-precision trapezoid and more than 128 trapezoid intervals.
+template <typename R> inline int cooperating_lanes(const LgarDims *dims, unsigned simds) {
+  if (sizeof(R) != 8 || dims->search_mode == 0 || dims->use_closed_form_G || dims->geff_mode != 0) return 1;
+  if (dims->nint > LGAR_COOP_TAB) return 1;  // the groups' LDS tables hold one head / node per trapezoid interval
+  if (dims->forward_lanes > 0) return dims->forward_lanes;
+  if (dims->search_mode == 2) return 1;      // the capacity chain was asked for (tests): plain kernels
+  const size_t groups = ((size_t)dims->n_columns + simds - 1) / simds;  // columns a wavefront has to take
+  return groups <= LGAR_COOP_GROUPS ? (int)(WAVE / groups) : 1;         // 64, 32, 21, 16, 12, 10, 9, 8, 7, 6, 5, 5, 4, 4, 4, 4
+}
+
 
 inline int launch_status() {
   hipError_t e = hipGetLastError();

@@ -85,6 +85,11 @@ extern "C" {
 const char *lgar_version(void) { return "lgar-hip 0.2 (gfx950)"; }
 int32_t lgar_fmax(void) { return LGAR_FMAX; }
 int32_t lgar_lmax(void) { return LGAR_LMAX; }
+int32_t lgar_cooperating_lanes(const LgarDims *dims, int32_t dtype) {
+  if (check_dims(dims) != 0 || (dtype != LGAR_F32 && dtype != LGAR_F64)) return LGAR_E_ARG;
+  // (the function forward_typed itself calls, lgar_host.hpp)
+  return dtype == LGAR_F64 ? cooperating_lanes<double>(dims, wave_slots(1)) : cooperating_lanes<float>(dims, wave_slots(1));
+}
 
 int32_t lgar_state_init(const LgarDims *dims, const LgarParams *params, LgarState *state, int32_t *status, int32_t dtype,
                         void *stream) {

@@ -63,9 +63,10 @@ __global__ __launch_bounds__(WAVE, (Occupancy<R, CAP>::waves)) void lgar_forward
   // With a ticket counter: persistent waves.  The grid is one wave per wave slot of the chip; each pulls 64-column blocks
   // from the counter until none is left, so no round of the grid is partially filled whatever the column count.
   // Without: one workgroup per block.
-  // cooperating lanes: `coop` adjacent lanes per column (a power of two; 1 = every lane its own column)
+  // cooperating lanes: `coop` adjacent lanes per column (4..64; 1 = every lane its own column), 64 / coop columns per wave
   const int coop = CoopLDS<R, MODE>::on ? ap->coop : 1;
-  const unsigned nblocks = (unsigned)((N * (size_t)coop + WAVE - 1) / WAVE);
+  const unsigned cpb = (unsigned)(WAVE / coop);
+  const unsigned nblocks = (unsigned)((N + cpb - 1) / cpb);
   for (bool first = true;; first = false) {
     unsigned blk = blockIdx.x;
     if (ticket != nullptr) {
@@ -77,9 +78,13 @@ __global__ __launch_bounds__(WAVE, (Occupancy<R, CAP>::waves)) void lgar_forward
     }
     if constexpr (CoopLDS<R, MODE>::on) {
       if (coop > 1) {
-        const size_t c0 = ((size_t)blk * WAVE + lane) / (size_t)coop;
+        // my group and my place in it; the lanes left over when coop does not divide 64 join the last group
+        int group = lane / coop;
+        group = group < (int)cpb ? group : (int)cpb - 1;
+        const int rank = lane - group * coop;
+        const size_t c0 = (size_t)blk * cpb + group;
         const bool live = c0 < N;
-        forward_lane<R, NL, CAP, MODE>(ap, live ? c0 : N - 1, live, lane, lds, (lane & (coop - 1)) == 0, &coop_lds.tab[lane / coop][0]);
+        forward_lane<R, NL, CAP, MODE>(ap, live ? c0 : N - 1, live, lane, lds, rank == 0, &coop_lds.tab[group][0], group, rank);
         continue;
       }
     }
@@ -131,23 +136,12 @@ static int init_typed(const LgarDims *dims, const LgarParams *params, LgarState 
   return launch_status();
 }
 
-// wave slots of the chip for a kernel compiled for `waves` waves per SIMD
-static unsigned wave_slots(int waves) {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-      n = 256;
-    cus = n;
-  }
-  return (unsigned)cus * 4u * (unsigned)waves;
-}
-
 template <typename R, int NL, int CAP, int MODE>
 static void launch_forward_kernel(KArgs<R> &a, unsigned nblocks, unsigned *ticket, hipStream_t st) {
   a.ticket = ticket;
   if (!CoopLDS<R, MODE>::on) a.coop = 1;
-  nblocks = (unsigned)(((size_t)a.N * (size_t)a.coop + WAVE - 1) / WAVE);
+  const unsigned cpb = (unsigned)(WAVE / a.coop);  // columns per wavefront
+  nblocks = (unsigned)(((size_t)a.N + cpb - 1) / cpb);
   unsigned grid = nblocks;
   if (ticket != nullptr) {
     const unsigned slots = wave_slots(Occupancy<R, CAP>::waves);
@@ -172,21 +166,6 @@ static void launch_fast_kernel(KArgs<R> &a, unsigned nblocks, unsigned *ticket, 
   }
   (void)mixed;
   launch_forward_kernel<R, NL, CAP, 1>(a, nblocks, ticket, st);
-}
-
-// lanes per column for this job: LgarDims.forward_lanes when given, else the largest power of two <= 64 that keeps the job
-// within ONE wave per SIMD (n_columns * lanes / 64 <= simds) -- two such waves on a SIMD contend for its vector ALU in the
-// trapezoid and the gain is gone (measured: 10 000 columns x 8 lanes = 1250 waves run slower than 157 plain ones).  The
-// answer is 1, 4, 8, 16, 32 or 64 (the groups' LDS tables exist for at most 16 groups per wave: not 2); always 1 for fp32,
-// closed-form G, the literal mode, the mixed-precision trapezoid and more than 128 trapezoid intervals.
-template <typename R> static int cooperating_lanes(const LgarDims *dims, unsigned simds) {
-  if (sizeof(R) != 8 || dims->search_mode == 0 || dims->use_closed_form_G || dims->geff_mode != 0) return 1;
-  if (dims->nint > LGAR_COOP_TAB) return 1;  // the groups' LDS tables hold one head / node per trapezoid interval
-  if (dims->forward_lanes > 0) return dims->forward_lanes;
-  if (dims->search_mode == 2) return 1;      // the capacity chain was asked for (tests): plain kernels
-  int lanes = 1;
-  while (lanes < WAVE && ((size_t)dims->n_columns * (size_t)(lanes * 2) + WAVE - 1) / WAVE <= (size_t)simds) lanes *= 2;
-  return lanes >= 4 ? lanes : 1;
 }
 
 // The front-capacity chain of one lgar_forward call (see lgar_forward_body.hpp).

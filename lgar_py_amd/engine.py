@@ -301,6 +301,10 @@ class LgarEngine:
         _capi.check(rc, "lgar_forward_tangent")
         return grad, ser, st
 
+    def cooperating_lanes(self):
+        """Lanes per column lgar_forward uses for this engine's job (1, or 4..64 for fp64 jobs under one wave per SIMD)."""
+        return int(self.lib.lgar_cooperating_lanes(C.byref(self.dims), self._dt))
+
     def geff_wave_calls(self, reset=True):
         """Wave-level Geff evaluations since the last reset (measurement: LgarStepOut.counters[0])."""
         n = int(self.counters[0].item())

@@ -107,3 +107,30 @@ def test_integration_md_stub_matches_the_ctypes_mirror():
         m = re.search(r"for k in \(([^)]*)\)", line)
         doc = [x.strip().strip('"') for x in m.group(1).split(",")] if m else re.findall(r'\("(\w+)"', line)
         assert doc == [f[0] for f in getattr(_capi, cls)._fields_], cls
+
+
+def test_library_choice_of_cooperating_lanes():
+    """lgar_cooperating_lanes (host logic, no GPU needed): fp64 jobs under one wave per SIMD get as many lanes per column as
+    keep them there -- ceil(N / 1024) columns per wavefront, 64 // that lanes each, at most 16 columns per wavefront -- and
+    everything else one lane per column."""
+    from lgar_py_amd import _capi
+    lib = _capi.load()
+    d = _capi.LgarDims()
+    d.n_layers, d.num_subcycles, d.nint, d.n_giuh, d.search_mode, d.dt_h = 3, 1, 120, 5, 1, 1.0
+
+    def lanes(n, dtype=_capi.F64, **kw):
+        d.n_columns = n
+        d.forward_lanes, d.geff_mode, d.use_closed_form_G, d.search_mode, d.nint = 0, 0, 0, 1, 120
+        for k, v in kw.items():
+            setattr(d, k, v)
+        return lib.lgar_cooperating_lanes(C.byref(d), dtype)
+
+    assert [lanes(n) for n in (1, 64, 1024, 1025, 2048, 3000, 10_000, 16_384, 16_385, 1 << 20)] == [64, 64, 64, 32, 32, 21, 6, 4, 1, 1]
+    assert lanes(10_000, _capi.F32) == 1                 # fp32: no cooperating kernels
+    assert lanes(100, geff_mode=1) == 1                  # mixed-precision trapezoid
+    assert lanes(100, use_closed_form_G=1) == 1          # no trapezoid at all
+    assert lanes(100, search_mode=0) == 1                # the literal mode
+    assert lanes(100, search_mode=2) == 1                # the capacity chain was asked for
+    assert lanes(100, nint=200) == 1                     # more intervals than the groups' LDS tables hold
+    assert lanes(1 << 20, forward_lanes=8) == 8 and lanes(5, forward_lanes=1) == 1   # the caller's word
+    assert lanes(5, forward_lanes=3) < 0                 # rejected (LGAR_E_ARG): a group has at least 4 lanes

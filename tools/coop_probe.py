@@ -37,7 +37,7 @@ def run(N, lanes, T=3000, reps=2):
 
 for N in (10000, 1, 64, 1000):
     base = None
-    for lanes in (1, 4, 8, 16, 32, 64, 0):
+    for lanes in (1, 4, 6, 8, 16, 64, 0):
         if N * max(lanes, 1) > 64 * 4096:
             continue
         ms, out, eng = run(N, lanes)
