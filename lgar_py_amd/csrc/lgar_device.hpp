@@ -48,6 +48,7 @@ __device__ __forceinline__ double pw(double x, double y) { return fast_pow(x, y)
 __device__ __forceinline__ float lg2(float x) { return __builtin_amdgcn_logf(x); }
 __device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float sq(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float clamp01(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f); }  // v_med3_f32
 __device__ __forceinline__ unsigned long long any_lane(bool p) { return __ballot(p); }
 __device__ __forceinline__ bool first_active_lane() {
   const unsigned long long m = __ballot(1);
@@ -57,6 +58,7 @@ __device__ __forceinline__ bool first_active_lane() {
 __device__ __forceinline__ float lg2(float x) { return log2f(x); }
 __device__ __forceinline__ float ex2(float x) { return exp2f(x); }
 __device__ __forceinline__ float sq(float x) { return sqrtf(x); }
+__device__ __forceinline__ float clamp01(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
 __device__ __forceinline__ unsigned long long any_lane(bool p) { return p ? 1ull : 0ull; }
 __device__ __forceinline__ bool first_active_lane() { return true; }
 #endif
@@ -590,11 +592,12 @@ template <> __device__ __forceinline__ double geff<double>(const LayerK<double> 
 //   * both heads h(Se) (calc_h_from_se, utils.py:159-174), dh, and the two END nodes K(Se_i), K(Se_f)
 //     (calc_k_from_se, utils.py:134-156) are double precision.  K falls steeply with h (like h^-3.7 for the bundled soils),
 //     so over a wide range the wet end node carries most of the sum: it must not carry fp32 rounding;
-//   * interior node j sits at x_j = alpha h_i + j alpha dh, formed in double and rounded once to fp32; the exponents
+//   * interior node j sits at x_j = alpha h_i + j alpha dh, formed from fp32 hi + lo pairs of both terms (within 1 ulp of
+//     the double-precision value); the exponents
 //     n - 1 and -m/2 enter as fp32 pairs hi + lo (their rounding would otherwise be a SYSTEMATIC relative error of
 //     ~1e-7 |log2 x| in every node; what remains -- the 1-ulp errors of v_log_f32 / v_exp_f32 and of x -- is random from
 //     node to node and averages over the sum);
-//   * the nodes' K_r are added up in double (per node pair: one fp32 add, one convert, one fp64 add).
+//   * the nodes' K_r are added up in double (per group of four nodes: two fp32 adds, one convert, one fp64 add).
 // Per interior node: the fp32 node's 4 transcendentals + ~6 packed/scalar fp32 operations + 2 fp64 operations, against the
 // ~93 fp64 instructions of the fused fp64 node.  The |h| < 0.1 -> Se = 1 rule and the wave-uniform select-free prefix are
 // those of the fp32 loop above; as there, a node pair always goes through the same operations into the same accumulator,
@@ -605,11 +608,36 @@ __device__ __forceinline__ double kr_from_se(const LayerK<double> &l, double se)
   const double t = 1.0 - pw(base, l.m);
   return sqrt(se) * (t * t);
 }
+// One end of the trapezoid in double precision: h(Se) (calc_h_from_se, utils.py:159-174) and K(Se) / Ksat (calc_k_from_se,
+// utils.py:134-156) from SHARED logarithms.  With q = log2 Se^(1/m), C = 2^q and u = log2(1 - C):
+//     K_r = sqrt(Se) (1 - 2^(m u))^2,     h = (1/alpha) 2^((u - q)/n)      [Se^(-1/m) - 1 = (1 - C)/C]
+// i.e. two logarithms and three exponentials where the two functions on their own take four pows.  The reference's nudges
+// (|base| <= 1e-8 -> base + 1e-12, both functions) are reproduced: at Se == 1 both bases are exactly 0 and share the
+// logarithm of 1e-12; a base in (0, 1e-8] (Se within 1e-8 of 1 but not 1) takes its own logarithm on a wave-uniform branch.
+__device__ __forceinline__ void mixed_end(const LayerK<double> &l, double se, double &h, double &kr) {
+  const double q = lg2(se) * l.inv_m;
+  const double C = ex2(q);  // Se^(1/m)
+  const double omc = 1.0 - C;
+  const bool k_nudged = fabs(omc) <= 1e-8;
+  const double bk = k_nudged ? omc + 1e-12 : omc;
+  const double u = lg2(bk);
+  const double t = 1.0 - ex2(l.m * u);
+  kr = sqrt(se) * (t * t);
+  const double bh = omc / C;  // Se^(-1/m) - 1
+  const bool h_nudged = fabs(bh) <= 1e-8;
+  double lbh = (omc == 0.0) ? u : u - q;  // log2 of the (nudged) base of h
+  if (any_lane((k_nudged || h_nudged) && omc != 0.0) != 0ull) {
+    const double own = lg2(h_nudged ? bh + 1e-12 : bh);
+    lbh = ((k_nudged || h_nudged) && omc != 0.0) ? own : lbh;
+  }
+  h = (1.0 / l.alpha) * ex2(lbh * l.inv_n);
+}
 __device__ __forceinline__ double geff_mixed(const LayerK<double> &l, double theta1, double theta2, int nint) {
   const double se_i = se_from_theta(l, theta1);
   const double se_f = se_from_theta(l, theta2);
-  const double h_i = h_from_se(l, se_i);
-  const double h_f = h_from_se(l, se_f);
+  double h_i, h_f, k0, kn_own;
+  mixed_end(l, se_i, h_i, k0);
+  mixed_end(l, se_f, h_f, kn_own);
   const double dh = (h_f - h_i) / double(nint);
   const double x0 = l.alpha * h_i, dx = l.alpha * dh, xcut = 0.1 * l.alpha;
   // exponents as fp32 pairs
@@ -673,37 +701,60 @@ __device__ __forceinline__ double geff_mixed(const LayerK<double> &l, double the
     t.y = (w.y > 0.875f) ? ts.y : t.y;                                                      \
     (TT) = t * t;                                                                           \
   }
-  double acc = 0.0, accb = 0.0;  // node pairs with even / odd index
+  // node abscissae x_j = x0 + j dx in fp32 from hi + lo pairs of x0 and dx: t = fma(j, dx_hi, x0_hi) is rounded once (and is
+  // exact where x0 and j dx cancel), the lo parts restore what the hi parts dropped; x_j is within 1 ulp of the double-precision
+  // value rounded to fp32 (the node's own v_log_f32 error is ten times that)
+  const float x0h = (float)x0, dxh = (float)dx;
+  const float x0l = (fabsf(x0h) < __builtin_inff()) ? (float)(x0 - (double)x0h) : 0.0f;
+  const float dxl = (fabsf(dxh) < __builtin_inff()) ? (float)(dx - (double)dxh) : 0.0f;
+  const f32x2 x0h2 = {x0h, x0h}, x0l2 = {x0l, x0l}, dxh2 = {dxh, dxh}, dxl2 = {dxl, dxl};
+  const f32x2 four2 = {4.0f, 4.0f};
+  double sum = 0.0;
   int it = 0;
-  double j0 = 1.0;  // index of the first node of the current pair, as a double (no integer -> double conversion per iteration)
-  for (; it + 1 < safe_pairs; it += 2, j0 += 4.0) {  // four nodes per iteration: two independent chains
-    const f32x2 xa = {(float)fma(j0, dx, x0), (float)fma(j0 + 1.0, dx, x0)};
-    const f32x2 xb = {(float)fma(j0 + 2.0, dx, x0), (float)fma(j0 + 3.0, dx, x0)};
-    f32x2 sa, ta, sb, tb;
-    LGAR_GEFFM_PAIR(xa, sa, ta)
-    const f32x2 ka = sa * ta;
-    acc = acc + (double)(ka.x + ka.y);
-    LGAR_GEFFM_PAIR(xb, sb, tb)
-    const f32x2 kb = sb * tb;
-    accb = accb + (double)(kb.x + kb.y);
+  f32x2 ja = {1.0f, 2.0f}, jb = {3.0f, 4.0f};  // node indices of the current pairs: small integers, exact in fp32
+  // four nodes per iteration, two independent chains; their K_r are added in fp32 ({K_j + K_j+2, K_j+1 + K_j+3}, then the two
+  // halves) and the group's sum goes into the double-precision accumulator.  Groups whose nodes may fall under the
+  // |h| < 0.1 cut (wave-uniform test) take K_r = ksat1 there: the same operations otherwise, so a column's result does not
+  // depend on its wavefront
+#define LGAR_GEFFM_GROUP(CUT)                                                               \
+  {                                                                                         \
+    const f32x2 xa = __builtin_elementwise_fma(ja, dxh2, x0h2) + __builtin_elementwise_fma(ja, dxl2, x0l2); \
+    const f32x2 xb = __builtin_elementwise_fma(jb, dxh2, x0h2) + __builtin_elementwise_fma(jb, dxl2, x0l2); \
+    f32x2 sa, ta, sb, tb;                                                                   \
+    LGAR_GEFFM_PAIR(xa, sa, ta)                                                             \
+    if (CUT) {                                                                              \
+      sa.x = (xa.x < xcutf) ? ksat1f : sa.x;                                                \
+      ta.x = (xa.x < xcutf) ? 1.0f : ta.x;                                                  \
+      sa.y = (xa.y < xcutf) ? ksat1f : sa.y;                                                \
+      ta.y = (xa.y < xcutf) ? 1.0f : ta.y;                                                  \
+    }                                                                                       \
+    const f32x2 ka = sa * ta;                                                               \
+    LGAR_GEFFM_PAIR(xb, sb, tb)                                                             \
+    if (CUT) {                                                                              \
+      sb.x = (xb.x < xcutf) ? ksat1f : sb.x;                                                \
+      tb.x = (xb.x < xcutf) ? 1.0f : tb.x;                                                  \
+      sb.y = (xb.y < xcutf) ? ksat1f : sb.y;                                                \
+      tb.y = (xb.y < xcutf) ? 1.0f : tb.y;                                                  \
+    }                                                                                       \
+    const f32x2 kb = __builtin_elementwise_fma(sb, tb, ka);                                 \
+    sum = sum + (double)(kb.x + kb.y);                                                      \
   }
-  for (; it < pairs; it++, j0 += 2.0) {  // the odd safe pair and the nodes that may fall under the |h| < 0.1 cut: K_r = ksat1 there
-    const f32x2 x = {(float)fma(j0, dx, x0), (float)fma(j0 + 1.0, dx, x0)};
+  for (; it + 1 < safe_pairs; it += 2, ja = ja + four2, jb = jb + four2) LGAR_GEFFM_GROUP(false)
+  for (; it + 1 < pairs; it += 2, ja = ja + four2, jb = jb + four2) LGAR_GEFFM_GROUP(true)
+#undef LGAR_GEFFM_GROUP
+  if (it < pairs) {  // an odd number of pairs: the last one alone
+    const f32x2 x = __builtin_elementwise_fma(ja, dxh2, x0h2) + __builtin_elementwise_fma(ja, dxl2, x0l2);
     f32x2 sr, tt;
     LGAR_GEFFM_PAIR(x, sr, tt)
-    if (it >= safe_pairs) {
-      sr.x = (x.x < xcutf) ? ksat1f : sr.x;
-      tt.x = (x.x < xcutf) ? 1.0f : tt.x;
-      sr.y = (x.y < xcutf) ? ksat1f : sr.y;
-      tt.y = (x.y < xcutf) ? 1.0f : tt.y;
-    }
+    sr.x = (x.x < xcutf) ? ksat1f : sr.x;
+    tt.x = (x.x < xcutf) ? 1.0f : tt.x;
+    sr.y = (x.y < xcutf) ? ksat1f : sr.y;
+    tt.y = (x.y < xcutf) ? 1.0f : tt.y;
     const f32x2 k = sr * tt;
-    if (it & 1) accb = accb + (double)(k.x + k.y);
-    else acc = acc + (double)(k.x + k.y);
+    sum = sum + (double)(k.x + k.y);
   }
-  double sum = acc + accb;
   if (M & 1) {  // odd number of interior nodes: the last one alone
-    const float x = (float)fma(double(M), dx, x0);
+    const float x = __builtin_fmaf(float(M), dxh, x0h) + __builtin_fmaf(float(M), dxl, x0l);
     const f32x2 xx = {x, x};
     f32x2 sr, tt;
     LGAR_GEFFM_PAIR(xx, sr, tt)
@@ -712,9 +763,8 @@ __device__ __forceinline__ double geff_mixed(const LayerK<double> &l, double the
 #undef LGAR_GEFFM_PAIR
   // end nodes in double precision, with the reference's own formulas (|h| < 0.1 -> Se = 1 applies to the LAST node only:
   // the first node's K is calc_k_from_se(Se_i) as it stands, green_ampt.py:60)
-  const double k0 = kr_from_se(l, se_i);
   // (the last node's Se is Se(h(Se_f)) in the reference: Se_f up to the rounding of the round trip)
-  const double kn = (fabs(h_f) < 0.1 || h_f < 0.0) ? ksat1 : kr_from_se(l, se_f);
+  const double kn = (fabs(h_f) < 0.1 || h_f < 0.0) ? ksat1 : kn_own;
   const double res = fabs((0.5 * dh) * ((k0 + kn) + 2.0 * sum));
   const bool outside = is_nan(h_i) || is_nan(h_f);
   return outside ? res + (h_i + h_f) : res;

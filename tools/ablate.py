@@ -33,6 +33,7 @@ VARIANTS = {
     "site1_le8": ["-DLGAR_COUNT_SITE=1", "-DLGAR_COUNT_MAXLANES=8"], "site1_le48": ["-DLGAR_COUNT_SITE=1", "-DLGAR_COUNT_MAXLANES=48"],
     "site2_waves": ["-DLGAR_COUNT_SITE=2"], "site2_lanes": ["-DLGAR_COUNT_SITE=2", "-DLGAR_COUNT_LANES"],  # dry depth
     "site3_waves": ["-DLGAR_COUNT_SITE=3"], "site3_lanes": ["-DLGAR_COUNT_SITE=3", "-DLGAR_COUNT_LANES"],  # insert_water
+    "mx_x64": ["-DLGAR_X_MIXED_X64"], "mx_sum4": ["-DLGAR_X_MIXED_SUM4"], "mx_ends4": ["-DLGAR_X_MIXED_ENDS4"], "mx_ends4_sum4": ["-DLGAR_X_MIXED_ENDS4", "-DLGAR_X_MIXED_SUM4"], "mx_il": ["-DLGAR_X_MIXED_IL"],
     "occ3": ["-DLGAR_OCC_F32_SMALL=3"],
     "occ2": ["-DLGAR_OCC_F32_SMALL=2"],
     "occ1_f64": ["-DLGAR_OCC_F64_SMALL=1"],
@@ -45,12 +46,13 @@ import numpy as np, torch
 import lgar_py_amd as lg
 from lgar_py_amd import workloads as W
 dtype = torch.float32 if %(dt)r == "f32" else torch.float64
+kw = {"geff_precision": "f32"} if %(dt)r == "mix" else {}
 N = %(n)d
 f = W.synth1_forcing(); T = f.shape[0]
 P = W.perturbed_columns(N, seed=0)
 sc = torch.tensor(W.forcing_scale(N, seed=1000), device="cuda")
 eng = lg.LgarEngine(P["alpha"], P["n"], P["ksat"], P["theta_e"], P["theta_r"], P["thickness"], dt_h=300.0 / 3600.0,
-                    ponded_depth_max=0.0, dtype=dtype)
+                    ponded_depth_max=0.0, dtype=dtype, **kw)
 pr = (torch.tensor(f[:, 0], device="cuda")[:, None] * sc[None, :]).to(dtype).contiguous()
 pe = torch.zeros_like(pr)
 out = {"runoff": torch.empty(T, N, dtype=dtype, device="cuda"), "percolation": torch.empty(T, N, dtype=dtype, device="cuda")}
