@@ -45,9 +45,11 @@ def _stale(lib=None, extra=()):
         return fh.read().strip() != _fingerprint(extra)
 
 
-def _stamp(lib, extra=()):
+def _stamp(lib, fingerprint):
+    """Record what the library was built FROM: the fingerprint taken before the first compile (a source edited while the
+    compilers ran must leave a stale stamp, not a fresh one)."""
     with open(lib + ".sha256", "w") as fh:
-        fh.write(_fingerprint(extra) + "\n")
+        fh.write(fingerprint + "\n")
 
 
 @contextlib.contextmanager
@@ -128,9 +130,10 @@ def build_variant(name, extra_flags, verbose=False, layers=(3,), tangent=False):
     with _locked(out):
         if not _stale(out, extra_flags):
             return out
+        fp = _fingerprint(extra_flags)
         hipcc, objs = _compile_all(units, os.path.join(vdir, "obj_" + name), "", flags, verbose)
         _link(hipcc, objs, out, verbose)
-        _stamp(out, extra_flags)
+        _stamp(out, fp)
     return out
 
 
@@ -147,7 +150,8 @@ def build(force=False, verbose=False):
         objroot = os.path.join(CSRC, "obj")
         if force and os.path.isdir(objroot):
             shutil.rmtree(objroot)
+        fp = _fingerprint()
         hipcc, objs = _compile_all(UNITS, objroot, "", [], verbose)
         _link(hipcc, objs, LIB, verbose)
-        _stamp(LIB)
+        _stamp(LIB, fp)
     return LIB

@@ -614,13 +614,14 @@ __device__ __forceinline__ double kr_from_se(const LayerK<double> &l, double se)
 // i.e. two logarithms and three exponentials where the two functions on their own take four pows.  The reference's nudges
 // (|base| <= 1e-8 -> base + 1e-12, both functions) are reproduced: at Se == 1 both bases are exactly 0 and share the
 // logarithm of 1e-12; a base in (0, 1e-8] (Se within 1e-8 of 1 but not 1) takes its own logarithm on a wave-uniform branch.
+#define LGAR_LOG2_1EM12 -39.863137138648355  // log2(1e-12): the nudged base at Se == 1
 __device__ __forceinline__ void mixed_end(const LayerK<double> &l, double se, double &h, double &kr) {
   const double q = lg2(se) * l.inv_m;
   const double C = ex2(q);  // Se^(1/m)
   const double omc = 1.0 - C;
   const bool k_nudged = fabs(omc) <= 1e-8;
   const double bk = k_nudged ? omc + 1e-12 : omc;
-  const double u = lg2(bk);
+  const double u = (omc == 0.0) ? LGAR_LOG2_1EM12 : lg2(bk);  // (the constant: the saturated end below takes the same value)
   const double t = 1.0 - ex2(l.m * u);
   kr = sqrt(se) * (t * t);
   const double bh = omc / C;  // Se^(-1/m) - 1
@@ -635,18 +636,23 @@ __device__ __forceinline__ void mixed_end(const LayerK<double> &l, double se, do
 __device__ __forceinline__ double geff_mixed(const LayerK<double> &l, double theta1, double theta2, int nint) {
   const double se_i = se_from_theta(l, theta1);
   const double se_f = se_from_theta(l, theta2);
+  // K_r at Se == 1 (the 1e-12 nudge of calc_k_from_se): (1 - (1e-12)^m)^2
+  const double tsat = 1.0 - ex2p(l.m * LGAR_LOG2_1EM12);
+  const double ksat1 = tsat * tsat;
+  const float ksat1f = (float)ksat1;
   double h_i, h_f, k0, kn_own;
   mixed_end(l, se_i, h_i, k0);
-  mixed_end(l, se_f, h_f, kn_own);
+  if (any_lane(se_f != 1.0) != 0ull) {
+    mixed_end(l, se_f, h_f, kn_own);
+  } else {  // every lane's wet end is saturated (theta_2 == theta_e: new fronts, infiltration): what mixed_end returns for Se == 1
+    h_f = (1.0 / l.alpha) * ex2(LGAR_LOG2_1EM12 * l.inv_n);
+    kn_own = ksat1;
+  }
   const double dh = (h_f - h_i) / double(nint);
   const double x0 = l.alpha * h_i, dx = l.alpha * dh, xcut = 0.1 * l.alpha;
   // exponents as fp32 pairs
   const double hmd = -0.5 * l.m;
   const float hm = (float)hmd, hm_lo = (float)(hmd - (double)hm);
-  // K_r at Se == 1 (the 1e-12 nudge of calc_k_from_se): (1 - (1e-12)^m)^2
-  const double tsat = 1.0 - ex2p(l.m * -39.863137138648355);
-  const double ksat1 = tsat * tsat;
-  const float ksat1f = (float)ksat1;
   const int M = nint - 1;  // interior nodes j = 1 .. nint-1
   const int pairs = M >> 1;
   const double jf = (x0 - xcut) / -dx - 1.5;
@@ -742,23 +748,20 @@ __device__ __forceinline__ double geff_mixed(const LayerK<double> &l, double the
   for (; it + 1 < safe_pairs; it += 2, ja = ja + four2, jb = jb + four2) LGAR_GEFFM_GROUP(false)
   for (; it + 1 < pairs; it += 2, ja = ja + four2, jb = jb + four2) LGAR_GEFFM_GROUP(true)
 #undef LGAR_GEFFM_GROUP
-  if (it < pairs) {  // an odd number of pairs: the last one alone
-    const f32x2 x = __builtin_elementwise_fma(ja, dxh2, x0h2) + __builtin_elementwise_fma(ja, dxl2, x0l2);
-    f32x2 sr, tt;
-    LGAR_GEFFM_PAIR(x, sr, tt)
-    sr.x = (x.x < xcutf) ? ksat1f : sr.x;
-    tt.x = (x.x < xcutf) ? 1.0f : tt.x;
-    sr.y = (x.y < xcutf) ? ksat1f : sr.y;
-    tt.y = (x.y < xcutf) ? 1.0f : tt.y;
-    const f32x2 k = sr * tt;
-    sum = sum + (double)(k.x + k.y);
-  }
-  if (M & 1) {  // odd number of interior nodes: the last one alone
-    const float x = __builtin_fmaf(float(M), dxh, x0h) + __builtin_fmaf(float(M), dxl, x0l);
-    const f32x2 xx = {x, x};
-    f32x2 sr, tt;
-    LGAR_GEFFM_PAIR(xx, sr, tt)
-    sum = sum + (double)((x < xcutf) ? ksat1f : sr.x * tt.x);
+  const int rem = M - 2 * it;  // interior nodes left over by the groups of four: 0..3 (3 for the reference's 120 intervals)
+  if (rem > 0) {             // ... as one more group whose surplus nodes count as zero
+    const f32x2 xa = __builtin_elementwise_fma(ja, dxh2, x0h2) + __builtin_elementwise_fma(ja, dxl2, x0l2);
+    const f32x2 xb = __builtin_elementwise_fma(jb, dxh2, x0h2) + __builtin_elementwise_fma(jb, dxl2, x0l2);
+    f32x2 sa, ta, sb, tb;
+    LGAR_GEFFM_PAIR(xa, sa, ta)
+    LGAR_GEFFM_PAIR(xb, sb, tb)
+    f32x2 ka = sa * ta, kb = sb * tb;
+    ka.x = (xa.x < xcutf) ? ksat1f : ka.x;
+    ka.y = (xa.y < xcutf) ? ksat1f : ka.y;
+    kb.x = (xb.x < xcutf) ? ksat1f : kb.x;
+    ka.y = (rem >= 2) ? ka.y : 0.0f;
+    kb.x = (rem >= 3) ? kb.x : 0.0f;
+    sum = sum + (double)((ka.x + kb.x) + ka.y);
   }
 #undef LGAR_GEFFM_PAIR
   // end nodes in double precision, with the reference's own formulas (|h| < 0.1 -> Se = 1 applies to the LAST node only:

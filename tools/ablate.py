@@ -2,7 +2,7 @@
 
 `python tools/ablate.py build` (CPU container: hipcc cross-compiles) builds measurement variants of liblgar_hip.so:
 duplication variants (-DLGAR_DUP_<X>: routine X runs twice, results unchanged => time delta = cost of X), skip variants
-and occupancy variants.  `python tools/ablate.py run [f32|f64] [columns]` (GPU box) times the bench workload's forward
+and occupancy variants.  `python tools/ablate.py run [f32|f64|mix] [columns]` (GPU box) times the bench workload's forward
 launch on each variant in a fresh child process and prints one JSON line per variant.
 """
 import json
@@ -33,7 +33,6 @@ VARIANTS = {
     "site1_le8": ["-DLGAR_COUNT_SITE=1", "-DLGAR_COUNT_MAXLANES=8"], "site1_le48": ["-DLGAR_COUNT_SITE=1", "-DLGAR_COUNT_MAXLANES=48"],
     "site2_waves": ["-DLGAR_COUNT_SITE=2"], "site2_lanes": ["-DLGAR_COUNT_SITE=2", "-DLGAR_COUNT_LANES"],  # dry depth
     "site3_waves": ["-DLGAR_COUNT_SITE=3"], "site3_lanes": ["-DLGAR_COUNT_SITE=3", "-DLGAR_COUNT_LANES"],  # insert_water
-    "mx_x64": ["-DLGAR_X_MIXED_X64"], "mx_sum4": ["-DLGAR_X_MIXED_SUM4"], "mx_ends4": ["-DLGAR_X_MIXED_ENDS4"], "mx_ends4_sum4": ["-DLGAR_X_MIXED_ENDS4", "-DLGAR_X_MIXED_SUM4"], "mx_il": ["-DLGAR_X_MIXED_IL"],
     "occ3": ["-DLGAR_OCC_F32_SMALL=3"],
     "occ2": ["-DLGAR_OCC_F32_SMALL=2"],
     "occ1_f64": ["-DLGAR_OCC_F64_SMALL=1"],
