@@ -1469,19 +1469,32 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
   }
 
   // calc_dzdt, Layer.py:1176-1252 (calc_bottom_sum :1557-1582): one Geff per moving front
+  // Every lane walks its OWN list of moving fronts: fronts that need no Geff (layer bottoms, delta_theta <= 0) are finished
+  // on the way, and the k-th moving front of every column meets the others' k-th in one evaluation of the trapezoid --
+  // columns whose moving fronts sit at different indices (one has crossed into the next layer, another has two fronts
+  // above a boundary) would otherwise take turns.  The fronts' dz/dt do not depend on one another, so the order is free.
   __device__ __forceinline__ void calc_dzdt(S h_p) {
-    for (int i = 0; i < nf - 1; i++) {
-      if (F.bottom(i)) { F.DZ(i) = S(R(0.0)); continue; }
-      const int k = F.layer(i);
-      const LayerK<S> lk = pick(P, k);
-      S theta_1 = F.TH(i + 1), theta_2 = F.TH(i);
-      if (k == 0 && val(theta_1) > val(theta_2)) status |= LGAR_ST_THETA_ORDER;  // Layer.py:1206-1208
-      S delta_theta = F.TH(i) - F.TH(i + 1);
-      S dzdt = S(R(0.0));
-      if (val(delta_theta) > R(0.0)) {
+    int i = -1;
+    for (;;) {
+      // advance to the next front that moves
+      bool found = false;
+      while (!found && ++i < nf - 1) {
+        if (F.bottom(i)) { F.DZ(i) = S(R(0.0)); continue; }
+        const bool top = F.layer(i) == 0;
+        if (top && val(F.TH(i + 1)) > val(F.TH(i))) status |= LGAR_ST_THETA_ORDER;  // Layer.py:1206-1208
+        if (val(F.TH(i) - F.TH(i + 1)) > R(0.0)) found = true;
+        else F.DZ(i) = S(R(0.0));
+      }
+      if (any_lane(found) == 0ull) break;
+      if (found) {
+        const int k = F.layer(i);
+        const LayerK<S> lk = pick(P, k);
+        S theta_1 = F.TH(i + 1), theta_2 = F.TH(i);
+        S delta_theta = F.TH(i) - F.TH(i + 1);
         S g = capillary_drive(lk, theta_1, theta_2, 1);
         if (is_nan(val(g))) status |= LGAR_ST_NAN;
         const S ki = front_k(i, lk);
+        S dzdt;
         if (k == 0) {
           dzdt = dv<POL>(S(R(1.0)), delta_theta) * (dv<POL>(lk.ksat * (g + h_p), F.Z(i)) + ki);
         } else {
@@ -1497,8 +1510,8 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
             }
           dzdt = dv<POL>(S(R(1.0)), delta_theta) * (dv<POL>(F.Z(i), den) + dv<POL>(lk.ksat * (g + h_p), F.Z(i)));
         }
+        F.DZ(i) = dzdt;
       }
-      F.DZ(i) = dzdt;
     }
   }
 
