@@ -154,9 +154,12 @@ typedef struct {
  *   are forward()'s return pair (models/dpLGAR.py:299).
  * basin: [LGAR_NACC][n_steps] fp64 or NULL; for every bit j set in basin_mask,
  *   basin[j][t] += sum over this launch's columns of weight[c] * accumulator_j[t][c]
- *   (the caller zeroes it; what MassBalance.report_mass / the agent's y_hat aggregate over a basin).  Reduced in the
- *   kernel (wave reduction + one fp64 atomic per wave and step): the [n_steps][n_columns] series need not exist.
- *   Summation order across waves is not fixed, so values can differ in the last bits between runs.
+ *   (the caller zeroes it; what MassBalance.report_mass / the agent's y_hat aggregate over a basin).  Where series[j]
+ *   is given as well, the sum is taken from the stored series by a second kernel on the same stream (one pass, fixed
+ *   summation order: the same bits on every run; ~1 % of the launch).  Without series[j] it is reduced inside the forward
+ *   kernels (wave reduction + one fp64 atomic per wave and step: no [n_steps][n_columns] array is needed, summation order
+ *   across waves is not fixed, ~10 % of an fp32 launch on 1M columns).  Calls that add into the same basin block must
+ *   be on one stream.
  * weights: [n_columns] (dtype) or NULL = 1: e.g. area fractions.
  * counters[0] += number of wave-level Geff evaluations (calc_geff, lgar/green_ampt.py:19-99) of the launch: what
  *   bench.py prices against the chip's measured transcendental issue rate. */

@@ -233,7 +233,19 @@ __device__ __forceinline__ void forward_lane(const LGAR_KARG KArgs<R> *ap, size_
     // more fronts than this kernel can hold: next kernel of the chain, or (last kernel) front overflow
     if (a.chain_last) { overflow_on_load = true; t_stop = -1; } else t_stop = t_begin;
   }
-  if (overflow_on_load) col.status |= LGAR_ST_OVERFLOW;
+  if (overflow_on_load) {
+    col.status |= LGAR_ST_OVERFLOW;
+    // no step of this column will run: its rows of the requested series read as zero (lgar_basin_reduce_kernel sums them).
+    // Only the last kernel of a chain rejects a column, and that is a kernel of the full capacity: the hot 8- and 16-front
+    // kernels do not carry this loop (in the 8-front fp32 kernel it cost 1.1 ms of 13.5 through register allocation alone)
+    if constexpr (FMAX == LGAR_FMAX) {
+      if (leader)
+        for (int t = t_begin; t < a.T; t++)
+#pragma unroll
+          for (int j = 0; j < LGAR_NACC; j++)
+            if (a.series[j]) a.series[j][(size_t)t * N + c] = R(0);
+    }
+  }
   // (No software prefetch of the next step's forcing: the two values would have to live in registers across a whole step
   // -- ~10^4 cycles of VALU work -- and at 128 VGPRs they end up as scratch traffic; the load latency of a step's own
   // forcing is covered by the other three waves of the SIMD.)

@@ -11,6 +11,8 @@ import torch
 from . import _capi
 from ._capi import ACC_NAMES, GMAX, LMAX, LMIN, NACC, NSCAL, LgarError
 
+BASIN_SCRATCH_BYTES = 8 << 30  # largest series buffer LgarEngine.forward allocates on its own behind a basin sum
+
 
 def _require_gpu(device):
     if not torch.cuda.is_available():
@@ -119,6 +121,7 @@ class LgarEngine:
         self.scalars = z(NSCAL, N)
         self.totals = z(NACC, N)
         self.counters = z(_capi.NCOUNTERS, dt=torch.int64)
+        self._basin_scratch = (0, {})  # series buffers behind basin sums whose series the caller did not ask for
         self.tickets = z(_capi.NTICKETS, dt=torch.int32)  # work counters of the persistent-wave schedule
 
         self._params = _capi.LgarParams(*[t.data_ptr() for t in (self.alpha, self.n, self.ksat, self.theta_e,
@@ -157,7 +160,7 @@ class LgarEngine:
 
         Returns {name: tensor[T, N]} for the requested per-step series (the model accumulators as they
         stand after each forward(), before MassBalance.change_mass zeroes them).  basin: names whose per-step sum over
-        this engine's columns (optionally weighted by weights[N]) is reduced inside the kernel; returned under
+        this engine's columns (optionally weighted by weights[N]) is reduced on the device; returned under
         "basin:<name>" as fp64 [T] tensors.  call_sums=True adds "call_sums": [NACC, N], the accumulators summed over this
         call's steps (rows 8, 9: latest ponded_water / ending_volume)."""
         if self._state is None:
@@ -185,6 +188,16 @@ class LgarEngine:
                 j = ACC_NAMES.index(nm)
                 so.basin_mask |= 1 << j
                 res["basin:" + nm] = block[j]
+                # a basin sum is taken from the stored series in one deterministic pass after the launch (include/lgar.h:
+                # LgarStepOut.basin); the in-kernel atomics are ~10x as expensive, so a name whose series the caller does
+                # not want still gets a scratch series (kept for the next call of the same shape) unless it would be huge
+                if not so.series[j] and T * self.N * self.totals.element_size() <= BASIN_SCRATCH_BYTES:
+                    if self._basin_scratch[0] != T:  # buffers of one call shape at a time
+                        self._basin_scratch = (T, {})
+                    scratch = self._basin_scratch[1].get(nm)
+                    if scratch is None:
+                        scratch = self._basin_scratch[1][nm] = torch.empty(T, self.N, dtype=self.dtype, device=self.device)
+                    so.series[j] = scratch.data_ptr()
             if weights is not None:
                 w = torch.as_tensor(weights).to(self.device, self.dtype).contiguous()
                 if tuple(w.shape) != (self.N,):
