@@ -398,7 +398,7 @@ def main():
         res = eng.forward(precip, pet, series=("runoff", "percolation"), out=out, basin=("runoff",), check=False)
         if i is not None:
             ev[i][1].record()
-        basin = res["basin:runoff"]  # basin runoff per timestep [T] (fp64), reduced in the kernel epilogue
+        basin = res["basin:runoff"]  # basin runoff per timestep [T] (fp64): lgar_basin_reduce_kernel over the stored series
         if dist_on:
             all_reduce(basin)  # the only exchange of the path
         return basin
@@ -456,7 +456,10 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                          "algorithmic_bytes_per_launch": b_alg * N * T,
-                         "kernel": kname, "kernel_ms": kern_ms, "alg_bytes_per_column_timestep": b_alg,
+                         "kernel": kname, "kernel_ms": kern_ms,
+                         "kernel_ms_covers": "HIP events around one lgar_forward call: the dominant kernel, the two ~5 us kernels of its "
+                                             "capacity chain and the ~0.13 ms basin pass over the stored runoff series",
+                         "alg_bytes_per_column_timestep": b_alg,
                          "note": "path is VALU bound, not HBM bound (~1e3 flop/B; see valu_roofline and DESIGN.md); "
                                  "alg bytes use SURVEY 8(d)'s figure (F_MAX=16 state)"},
             "faulted_columns": int(faulted.item()),

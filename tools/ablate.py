@@ -33,6 +33,10 @@ VARIANTS = {
     "site1_le8": ["-DLGAR_COUNT_SITE=1", "-DLGAR_COUNT_MAXLANES=8"], "site1_le48": ["-DLGAR_COUNT_SITE=1", "-DLGAR_COUNT_MAXLANES=48"],
     "site2_waves": ["-DLGAR_COUNT_SITE=2"], "site2_lanes": ["-DLGAR_COUNT_SITE=2", "-DLGAR_COUNT_LANES"],  # dry depth
     "site3_waves": ["-DLGAR_COUNT_SITE=3"], "site3_lanes": ["-DLGAR_COUNT_SITE=3", "-DLGAR_COUNT_LANES"],  # insert_water
+    "cf_o2": ["-O2"], "cf_maxilp": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
+    "cf_relaxocc": ["-mllvm", "-amdgpu-schedule-relaxed-occupancy=true"], "cf_nopostsched": ["-mllvm", "-enable-post-misched=0"],
+    "cf_nounroll": ["-fno-unroll-loops"], "cf_metricbias": ["-mllvm", "-amdgpu-schedule-metric-bias=30"], "cf_trackers": ["-mllvm", "-amdgpu-use-amdgpu-trackers"],
+    "cf_iterative": ["-mllvm", "-amdgpu-sched-strategy=iterative-minreg"], "cf_nohighrp": ["-mllvm", "-amdgpu-disable-unclustered-high-rp-reschedule"],
     "occ3": ["-DLGAR_OCC_F32_SMALL=3"],
     "occ2": ["-DLGAR_OCC_F32_SMALL=2"],
     "occ1_f64": ["-DLGAR_OCC_F64_SMALL=1"],
