@@ -598,16 +598,10 @@ template <> __device__ __forceinline__ double geff<double>(const LayerK<double> 
 //     ~1e-7 |log2 x| in every node; what remains -- the 1-ulp errors of v_log_f32 / v_exp_f32 and of x -- is random from
 //     node to node and averages over the sum);
 //   * the nodes' K_r are added up in double (per group of four nodes: two fp32 adds, one convert, one fp64 add).
-// Per interior node: the fp32 node's 4 transcendentals + ~6 packed/scalar fp32 operations + 2 fp64 operations, against the
-// ~93 fp64 instructions of the fused fp64 node.  The |h| < 0.1 -> Se = 1 rule and the wave-uniform select-free prefix are
-// those of the fp32 loop above; as there, a node pair always goes through the same operations into the same accumulator,
-// so a column's result does not depend on its wavefront.
-__device__ __forceinline__ double kr_from_se(const LayerK<double> &l, double se) {  // calc_k_from_se / Ksat
-  double base = 1.0 - pw(se, l.inv_m);
-  if (fabs(base) <= 1e-8) base = base + 1e-12;
-  const double t = 1.0 - pw(base, l.m);
-  return sqrt(se) * (t * t);
-}
+// Per interior node: five hardware transcendentals + ~12 packed fp32 operations (the node is written without the cancelling
+// difference 1 - (a/(1+a))^m of the fp32 loop: see LGAR_GEFFM_PAIR), against the ~93 fp64 instructions of the fused fp64 node.
+// The |h| < 0.1 -> Se = 1 rule and the wave-uniform select-free prefix are those of the fp32 loop above; as there, a group of
+// nodes always goes through the same operations in the same order, so a column's result does not depend on its wavefront.
 // One end of the trapezoid in double precision: h(Se) (calc_h_from_se, utils.py:159-174) and K(Se) / Ksat (calc_k_from_se,
 // utils.py:134-156) from SHARED logarithms.  With q = log2 Se^(1/m), C = 2^q and u = log2(1 - C):
 //     K_r = sqrt(Se) (1 - 2^(m u))^2,     h = (1/alpha) 2^((u - q)/n)      [Se^(-1/m) - 1 = (1 - C)/C]
