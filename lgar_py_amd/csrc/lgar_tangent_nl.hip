@@ -14,7 +14,18 @@ namespace lgar {
 
 __host__ __device__ inline unsigned columns_per_block(int share) { return share >= 2 ? (unsigned)((WAVE / share) * share) : (unsigned)WAVE; }
 
-template <typename R, int NL, int CAP, int MODE> __global__ __launch_bounds__(WAVE) void lgar_tangent_kernel(TArgs<R> a) {
+// Waves per SIMD the register allocator is held to.  The 8-front fp32 kernel needs 259 registers on its own -- three too many
+// for two waves -- and a single resident wave gets an issue slot only every ~7 cycles: held to 256, it
+// runs two waves per SIMD (backward pass of the 100 000-column ensemble 61.6 -> 44.7 ms).  The fp64 kernels stay at one wave:
+// their dual-number front table alone is 40 KB of LDS per wave.
+#ifndef LGAR_TAN_F32_WAVES
+#define LGAR_TAN_F32_WAVES 2
+#endif
+template <typename R, int CAP> struct TangentOccupancy {
+  static constexpr int waves = (sizeof(R) == 4 && CAP == LGAR_CAP_SMALL) ? LGAR_TAN_F32_WAVES : 1;
+};
+template <typename R, int NL, int CAP, int MODE>
+__global__ __launch_bounds__(WAVE, (TangentOccupancy<R, CAP>::waves)) void lgar_tangent_kernel(TArgs<R> a) {
   __shared__ WaveLDS<Dual<R>, CAP, 1> lds;
   __shared__ R xchg[LGAR_XCHG_WORDS];  // tangent_share: the lanes of a column exchange trapezoid nodes through it (lgar_dual.hpp)
   const int lane = threadIdx.x;

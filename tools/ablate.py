@@ -37,7 +37,7 @@ VARIANTS = {
     "cf_relaxocc": ["-mllvm", "-amdgpu-schedule-relaxed-occupancy=true"], "cf_nopostsched": ["-mllvm", "-enable-post-misched=0"],
     "cf_nounroll": ["-fno-unroll-loops"], "cf_metricbias": ["-mllvm", "-amdgpu-schedule-metric-bias=30"], "cf_trackers": ["-mllvm", "-amdgpu-use-amdgpu-trackers"],
     "cf_iterative": ["-mllvm", "-amdgpu-sched-strategy=iterative-minreg"], "cf_nohighrp": ["-mllvm", "-amdgpu-disable-unclustered-high-rp-reschedule"],
-    "tan_base": [], "tan_maxilp": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
+    "tan_base": [], "tan_maxilp": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"], "tan_f32w1": ["-DLGAR_TAN_F32_WAVES=1"],
     "occ3": ["-DLGAR_OCC_F32_SMALL=3"],
     "occ2": ["-DLGAR_OCC_F32_SMALL=2"],
     "occ1_f64": ["-DLGAR_OCC_F64_SMALL=1"],
