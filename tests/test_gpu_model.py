@@ -199,7 +199,7 @@ def test_basin_sums_two_ways(monkeypatch):
     import lgar_py_amd as lg
     from lgar_py_amd import engine as E
     from lgar_py_amd import workloads as W
-    for N, dtype, tol in ((5000, torch.float64, 1e-13), (9001, torch.float32, 1e-6)):
+    for N, dtype, tol in ((5000, torch.float64, 1e-13), (9001, torch.float32, 1e-6), (777, torch.float64, 1e-13)):  # 16-byte rows or not
         P = W.perturbed_columns(N, seed=5)
         sc = W.forcing_scale(N, 0.5, 1.0, seed=6)
         f = W.synth1_forcing()
