@@ -176,6 +176,12 @@ typedef struct {
 } LgarStepOut;
 
 const char *lgar_version(void);
+/* ABI revision of this header: bumped whenever a struct of this file changes size or layout or an entry point changes its
+ * argument list (3: LgarDims.geff_mode / forward_lanes, lgar_forward_tangent's `tickets`).  A caller compares it with the
+ * LGAR_ABI_VERSION it was compiled against, and lgar_sizeof_dims() with its own sizeof(LgarDims), before the first call. */
+#define LGAR_ABI_VERSION 3
+int32_t lgar_abi_version(void);
+int32_t lgar_sizeof_dims(void);
 int32_t lgar_fmax(void);
 int32_t lgar_lmax(void);
 /* Lanes per column lgar_forward would use for these dims and dtype (LgarDims.forward_lanes = 0: the library's choice for jobs

@@ -21,7 +21,8 @@ ACC_NAMES = ["precip", "PET", "AET", "infiltration", "runoff", "percolation", "g
 ST_NAN, ST_NEGBASE, ST_THETA_ORDER, ST_OVERFLOW, ST_ITERCAP, ST_BOTTOM, ST_STRUCT = 1, 2, 4, 8, 16, 32, 64
 STATUS_NAMES = {1: "NaN", 2: "negative pow base", 4: "theta order", 8: "front overflow", 16: "iteration cap",
                 32: "front reached domain bottom", 64: "structural error"}
-EXPORTS = ["lgar_version", "lgar_fmax", "lgar_lmax", "lgar_cooperating_lanes", "lgar_state_init", "lgar_forward", "lgar_forward_tangent",
+ABI_VERSION = 3  # LGAR_ABI_VERSION of include/lgar.h this binding mirrors
+EXPORTS = ["lgar_version", "lgar_abi_version", "lgar_sizeof_dims", "lgar_fmax", "lgar_lmax", "lgar_cooperating_lanes", "lgar_state_init", "lgar_forward", "lgar_forward_tangent",
            "lgar_leaf_batch", "lgar_valu_probe", "lgar_valu_probe_insts"]
 
 
@@ -81,6 +82,15 @@ def load():
         raise LgarError("cannot load %s: %s; there is no CPU fallback" % (path, e))
     p = C.POINTER
     i32, vp, dbl = C.c_int32, C.c_void_p, C.c_double
+    # an older library (a measurement variant selected with LGAR_LIB, a stale copy) would misread LgarDims or take garbage for
+    # an argument it does not know: refuse it before the first call
+    if not hasattr(lib, "lgar_abi_version"):
+        raise LgarError("%s predates lgar_abi_version(): rebuild it (ABI %d expected)" % (path, ABI_VERSION))
+    lib.lgar_abi_version.restype = i32
+    lib.lgar_sizeof_dims.restype = i32
+    if lib.lgar_abi_version() != ABI_VERSION or lib.lgar_sizeof_dims() != C.sizeof(LgarDims):
+        raise LgarError("%s has ABI %d / sizeof(LgarDims) %d, this binding needs %d / %d: rebuild it"
+                        % (path, lib.lgar_abi_version(), lib.lgar_sizeof_dims(), ABI_VERSION, C.sizeof(LgarDims)))
     lib.lgar_version.restype = C.c_char_p
     lib.lgar_fmax.restype = i32
     lib.lgar_lmax.restype = i32

@@ -119,18 +119,20 @@ def build_variant(name, extra_flags, verbose=False, layers=(3,), tangent=False):
     (select one at run time with LGAR_LIB=<path>); forward path of the given layer counts only unless tangent=True."""
     vdir = os.path.join(CSRC, "variants")
     out = os.path.join(vdir, "liblgar_hip_%s.so" % name)
-    if not _stale(out, extra_flags):
-        return out
     units = [u for u in UNITS if not u[2] or int(u[2][1:]) in layers]
     if not tangent:
         units = [u for u in units if u[0] != "lgar_tangent_nl.hip"]
     # -DLGAR_MEASURE: the measurement points of the device code take their definitions from csrc/lgar_measure.hpp
     flags = list(extra_flags) + ["-DLGAR_MEASURE", "-DLGAR_ONLY_LAYERS=%s" % "".join(str(n) for n in layers)] + \
             ([] if tangent else ["-DLGAR_NO_TANGENT"])
+    # the stamp covers everything that decides what is in the library: the layer counts and the tangent kernels too (the same
+    # name asked for again with other layers must be rebuilt, not returned as it is)
+    if not _stale(out, flags):
+        return out
     with _locked(out):
-        if not _stale(out, extra_flags):
+        if not _stale(out, flags):
             return out
-        fp = _fingerprint(extra_flags)
+        fp = _fingerprint(flags)
         hipcc, objs = _compile_all(units, os.path.join(vdir, "obj_" + name), "", flags, verbose)
         _link(hipcc, objs, out, verbose)
         _stamp(out, fp)

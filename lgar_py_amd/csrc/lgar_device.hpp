@@ -187,6 +187,14 @@ template <typename S, int POL = 0> __device__ __forceinline__ S theta_from_h(con
   S op = pwx<EX>(R(1.0) + ap, l.m);
   return (dv<POL>(S(R(1.0)), op) * (l.te - l.tr)) + l.tr;
 }
+// ... also handing out (alpha h)^n, the quantity that says how close to saturation the head is
+template <typename S, int POL = 0> __device__ __forceinline__ S theta_from_h_ap(const LayerK<S> &l, S h, S &ap) {
+  using R = real_t<S>;
+  constexpr bool EX = POL == 1;
+  ap = pwx<EX>(l.alpha * h, l.n);
+  S op = pwx<EX>(R(1.0) + ap, l.m);
+  return (dv<POL>(S(R(1.0)), op) * (l.te - l.tr)) + l.tr;
+}
 // calc_se_from_theta, utils.py:102-112
 template <typename S> __device__ __forceinline__ S se_from_theta(const LayerK<S> &l, S theta) {
   return (theta - l.tr) / (l.te - l.tr);
@@ -882,6 +890,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
   // insert_water's Geff of the last call and what it was computed from (see insert_water): layer -1 = nothing remembered
   S memo_theta, memo_g;
   int memo_layer = -1;
+  unsigned near_sat_fronts = 0u;  // fronts whose psi the fast modes must send through the reference's theta -> psi round trip
   S aet_psi_wp_memo;          // calc_aet's half-uptake head of this column (a function of the top layer's parameters only)
   bool aet_psi_wp_known = false;
   bool count_geff = false;              // measurement: count wave-level Geff evaluations in the unused upper bits of `status`
@@ -1159,6 +1168,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
   // "layers above" loops have static bounds, and layer 0's cheap closed-form update carries no search code.
   struct SweepCarry {
     int i, nf0, fdd;
+    unsigned near_sat;  // bit i: front i took its psi from the front below with (alpha psi)^n < 1e-6 (see psi_round_trip)
     S infiltration, aet;
     S on_z, on_th, on_ps;  // pre-sweep values of front i+1
   };
@@ -1173,8 +1183,12 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
       if (i < c.nf0 - 1) {
         if (i == last || feq(i, last)) {
           // deepest front of a layer: psi continuity with the layer below
-          F.TH(i) = theta_from_h<S, POL>(lk, F.PS(i + 1));
+          S ap;
+          F.TH(i) = theta_from_h_ap<S, POL>(lk, F.PS(i + 1), ap);
           F.PS(i) = F.PS(i + 1);
+          if constexpr (MODE != 0 && sizeof(R) == 8) {
+            if (__builtin_expect(val(ap) < R(1e-6), 0)) c.near_sat |= 1u << i;
+          }
         } else if constexpr (K == 0) {
           S prior_mass = oc_z * (oc_th - c.on_th);
           if (i == c.fdd || feq(c.fdd, i)) prior_mass = prior_mass + (c.infiltration - (R(0.0) + c.aet));
@@ -1260,8 +1274,10 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
     c.i = nf - 1; c.nf0 = nf; c.fdd = fdd;
     c.infiltration = infiltration; c.aet = aet;
     c.on_z = c.on_th = c.on_ps = S(R(0.0));
+    c.near_sat = 0u;
     sweep_from<NL - 1>(c);
     check_column_mass(fdd, old_mass, infiltration, aet);  // after front 0 (Layer.py:1296-1305)
+    near_sat_fronts = c.near_sat;
   }
 
   // merge_wetting_fronts / is_passing / pass_front / delete_front, Layer.py:826-892: per layer, the first
@@ -1452,6 +1468,20 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
       // the passes can leave psi inconsistent with theta (dry-over-wet in a deeper layer writes the psi of ANOTHER
       // layer's theta into the fronts above it, Layer.py:1117-1143): the reference's update_psi repairs that
       if constexpr (MODE != 0) update_psi();
+    } else if constexpr (MODE != 0 && sizeof(R) == 8) {
+      // A layer's deepest front takes the psi of the front below and theta(psi) of its own layer (Layer.py:389-418); the
+      // reference's update_psi then re-derives psi from that theta.  The round trip returns psi to ~eps / (alpha psi)^n
+      // relative: nothing a decision can see (the tie rule of calc_wetting_front_free_drainage has rtol 1e-5, atol 1e-8)
+      // unless the front is all but saturated -- (alpha psi)^n < 1e-6, psi below ~0.03 cm -- where the reference's psi is
+      // the round trip's noise and its tie rule decides on that noise (fixture crash_bottom_three_layer_synth3: 1.77e-7 cm
+      // comes back as 4.64e-6).  Those fronts, and only those, go through the same round trip here.
+      if (__builtin_expect(near_sat_fronts != 0u, 0)) {
+        for (int i = 0; i < nf - 1; i++)
+          if (near_sat_fronts & (1u << i)) {
+            const LayerK<S> lk = pick(P, F.layer(i));
+            F.PS(i) = h_from_se<S, POL>(lk, se_from_theta(lk, F.TH(i)));
+          }
+      }
     }
     // update_psi (Layer.py:1157-1174) re-derives psi from theta for every front but the deepest.  After the sweep alone
     // every front already carries psi = h(Se(theta)) (in-layer and base-case fronts) or the psi its theta was computed
@@ -1572,7 +1602,18 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
     // that holds for every column of the wavefront; same results either way).
     if (nf != NL) {
       const S theta_1 = F.TH(nxt_i < nf ? nxt_i : nf - 1);
-      if (memo_layer == kfp && same_bits(theta_1, memo_theta)) {
+      bool hit = memo_layer == kfp && same_bits(theta_1, memo_theta);
+      if constexpr (sizeof(S) != sizeof(R)) {
+        // Dual numbers: same_bits compares the tangent as well, the only place where a branch could depend on it.  The W
+        // lanes of a shared group (LgarDims.tangent_share) hold the same values and different tangents and must enter the
+        // trapezoid TOGETHER (geff_shared_blocks exchanges nodes between them): when any lane's tangent alone says "miss",
+        // every lane whose values match recomputes -- the same result as its memo, bit for bit.
+        if (share_lanes >= 2) {
+          const bool value_hit = memo_layer == kfp && val(theta_1) == val(memo_theta);
+          if (any_lane(value_hit && !hit) != 0ull) hit = false;
+        }
+      }
+      if (hit) {
         g = memo_g;
       } else {
         g = capillary_drive(lk, theta_1, lk.te, 3);

@@ -157,7 +157,9 @@ static int forward_by_layers(const LgarDims *dims, const LgarParams *params, Lga
 
 extern "C" {
 
-const char *lgar_version(void) { return "lgar-hip 0.2 (gfx950)"; }
+const char *lgar_version(void) { return "lgar-hip 0.4 (gfx950)"; }
+int32_t lgar_abi_version(void) { return LGAR_ABI_VERSION; }
+int32_t lgar_sizeof_dims(void) { return (int32_t)sizeof(LgarDims); }
 int32_t lgar_fmax(void) { return LGAR_FMAX; }
 int32_t lgar_lmax(void) { return LGAR_LMAX; }
 int32_t lgar_cooperating_lanes(const LgarDims *dims, int32_t dtype) {

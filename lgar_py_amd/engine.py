@@ -11,7 +11,7 @@ import torch
 from . import _capi
 from ._capi import ACC_NAMES, GMAX, LMAX, LMIN, NACC, NSCAL, LgarError
 
-BASIN_SCRATCH_BYTES = 8 << 30  # largest series buffer LgarEngine.forward allocates on its own behind a basin sum
+BASIN_SCRATCH_BYTES = 8 << 30  # most series memory, over ALL basin names, an engine allocates on its own behind basin sums
 
 
 def _require_gpu(device):
@@ -37,6 +37,12 @@ class LgarEngine:
     only) = mixed precision: fp64 column state, branches, mass bookkeeping, trapezoid heads and end nodes; the 119 interior
     nodes with the fp32 hardware transcendentals, summed in fp64 (LgarDims.geff_mode = 1; DESIGN.md section 4 states the
     tolerance this reaches against the reference).
+    forward_lanes: lanes per column in lgar_forward.  0 (default) = the library gives fp64 trapezoid jobs under one wave per
+    SIMD 4..64 cooperating lanes per column (same results bit for bit); 1 = never; 4..64 = exactly that many (a group needs
+    four lanes for the trapezoid's end points, so 2 and 3 do not exist).  Honoured by the fp64 fast modes with the native
+    trapezoid and nint <= 128 only; an explicit request that cannot be honoured raises.
+    basin_scratch_bytes: most series memory the engine may allocate on its own behind basin sums whose series the caller
+    did not ask for (see forward); 0 = never, such sums are taken by the in-kernel atomics instead.
     bottom_mode: 0 (default) = like the reference, a front reaching the domain bottom faults the column; 1 = it leaves
     the column as percolation (LGAR-C intent; parity unpinned, the reference crashes there).
     """
@@ -45,7 +51,7 @@ class LgarEngine:
                  initial_psi=2000.0, ponded_depth_max=0.0, wilting_point_psi=15495.0, frozen_factor=1.0, nint=120,
                  giuh_ordinates=(0.06, 0.51, 0.28, 0.12, 0.03), dtype=torch.float64, device="cuda:0",
                  iter_cap=0, search_mode=1, bottom_mode=0, use_closed_form_G=False, front_slots=None, with_state=True,
-                 geff_precision="native", forward_lanes=0):
+                 geff_precision="native", forward_lanes=0, basin_scratch_bytes=BASIN_SCRATCH_BYTES):
         self.device = torch.device(device)
         _require_gpu(self.device)
         self.lib = _capi.load()
@@ -98,9 +104,15 @@ class LgarEngine:
             raise LgarError("geff_precision='f32' is the mixed mode of the fp64 fast searches (dtype float64, search_mode 1 or 2)")
         d.geff_mode = 1 if geff_precision == "f32" else 0
         self.geff_precision = geff_precision
-        # lanes per column in lgar_forward: 0 = the library gives small fp64 jobs 2..64 cooperating lanes per column (same
-        # results bit for bit), 1 = never, 2..64 = exactly that many (tests)
-        d.forward_lanes = int(forward_lanes)
+        forward_lanes = int(forward_lanes)
+        if forward_lanes not in (0, 1) and not 4 <= forward_lanes <= 64:
+            raise LgarError("forward_lanes must be 0 (library's choice), 1, or 4..64 (got %d)" % forward_lanes)
+        if forward_lanes > 1 and (dtype != torch.float64 or int(search_mode) == 0 or geff_precision != "native"
+                                  or use_closed_form_G or int(nint) > 128):
+            raise LgarError("forward_lanes=%d cannot be honoured: cooperating lanes exist for the fp64 fast modes with the "
+                            "native trapezoid (no closed-form G, nint <= 128) only" % forward_lanes)
+        d.forward_lanes = forward_lanes
+        self.basin_scratch_bytes = int(basin_scratch_bytes)
         FMAX = int(front_slots) if front_slots else _capi.FMAX
         if not L + 1 <= FMAX <= _capi.FMAX:
             raise LgarError("front_slots must be in %d..%d" % (L + 1, _capi.FMAX))
@@ -142,6 +154,10 @@ class LgarEngine:
                                           self.status.data_ptr(), self._dt, self._stream())
         _capi.check(rc, "lgar_state_init")
 
+    def release_scratch(self):
+        """Free the series buffers forward() keeps behind basin sums (they come back on the next such call)."""
+        self._basin_scratch = (0, {})
+
     def _set_forcing_layout(self, precip, pet, forcing_group):
         g = max(1, int(forcing_group))
         if (precip.shape != pet.shape or precip.dim() != 2 or precip.shape[1] < 1 or self.N % g != 0
@@ -161,7 +177,11 @@ class LgarEngine:
         Returns {name: tensor[T, N]} for the requested per-step series (the model accumulators as they
         stand after each forward(), before MassBalance.change_mass zeroes them).  basin: names whose per-step sum over
         this engine's columns (optionally weighted by weights[N]) is reduced on the device; returned under
-        "basin:<name>" as fp64 [T] tensors.  call_sums=True adds "call_sums": [NACC, N], the accumulators summed over this
+        "basin:<name>" as fp64 [T] tensors.  MEMORY: a basin sum is taken from the stored series (one deterministic pass, ~10x
+        cheaper than in-kernel atomics), so a basin name that is not also in `series` gets a [T, N] scratch series of its own,
+        kept for the next call of the same T -- as long as all such buffers together stay within the engine's
+        basin_scratch_bytes (default 8 GiB; 0 = never); past that the sum falls back to the in-kernel atomics and nothing is
+        allocated.  release_scratch() frees them.  call_sums=True adds "call_sums": [NACC, N], the accumulators summed over this
         call's steps (rows 8, 9: latest ponded_water / ending_volume)."""
         if self._state is None:
             raise LgarError("this engine was created with with_state=False (tangent launches only)")
@@ -191,13 +211,15 @@ class LgarEngine:
                 # a basin sum is taken from the stored series in one deterministic pass after the launch (include/lgar.h:
                 # LgarStepOut.basin); the in-kernel atomics are ~10x as expensive, so a name whose series the caller does
                 # not want still gets a scratch series (kept for the next call of the same shape) unless it would be huge
-                if not so.series[j] and T * self.N * self.totals.element_size() <= BASIN_SCRATCH_BYTES:
+                if not so.series[j]:
                     if self._basin_scratch[0] != T:  # buffers of one call shape at a time
                         self._basin_scratch = (T, {})
                     scratch = self._basin_scratch[1].get(nm)
-                    if scratch is None:
+                    one = T * self.N * self.totals.element_size()
+                    if scratch is None and (len(self._basin_scratch[1]) + 1) * one <= self.basin_scratch_bytes:
                         scratch = self._basin_scratch[1][nm] = torch.empty(T, self.N, dtype=self.dtype, device=self.device)
-                    so.series[j] = scratch.data_ptr()
+                    if scratch is not None:
+                        so.series[j] = scratch.data_ptr()
             if weights is not None:
                 w = torch.as_tensor(weights).to(self.device, self.dtype).contiguous()
                 if tuple(w.shape) != (self.N,):

@@ -17,6 +17,25 @@ def golden_names():
     return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and f != "leaf_kats.npz")
 
 
+def check_fault_kind(g, status):
+    """The status bits a crash fixture must produce, by what the reference raised (crash_msg):
+    AttributeError ('NoneType' ... 'attributes', Layer.py:980: a front at the domain bottom) -> LGAR_ST_BOTTOM and no
+    NaN / negative-base bit; ValueError (a pow the reference refuses, physics/utils.py:17-27) -> NAN or NEGBASE and
+    no BOTTOM bit.  `status` may be an int or an array of per-column words."""
+    import numpy as np
+    st = np.atleast_1d(np.asarray(status)).astype(np.int64)
+    msg = str(g["crash_msg"])
+    NAN, NEGBASE, BOTTOM, STRUCT = 1, 2, 32, 64
+    if msg.startswith("AttributeError"):
+        assert ((st & BOTTOM) != 0).all(), (msg, st[:4])
+        assert ((st & (NAN | NEGBASE | STRUCT)) == 0).all(), (msg, st[:4])
+    elif msg.startswith("ValueError"):
+        assert ((st & (NAN | NEGBASE)) != 0).all(), (msg, st[:4])
+        assert ((st & BOTTOM) == 0).all(), (msg, st[:4])
+    else:
+        raise AssertionError("unclassified reference crash: " + msg)
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

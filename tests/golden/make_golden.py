@@ -492,6 +492,31 @@ CASES["crash_dry_over_wet_300"] = (run_case, dict(forcing=PH, soil=soil_, pdm=2,
                                                   forcing_scale=scale_, scale_pet=False))
 
 
+# A wetting front that reaches the bottom of the soil column: the reference dies with AttributeError ('NoneType' object has
+# no attribute 'attributes', Layer.py:980: recalibrate reads self.next_layer of the bottom layer).  The kernels stop such a
+# column with LGAR_ST_BOTTOM; these fixtures pin the STEP at which that must happen and the trajectory up to it.
+#   * the Phillipsburg soils with 4 cm layers under the synth_1 storm (SURVEY §8c saw step 98);
+#   * sand over silt loam, 14 + 26 cm, hourly Phillipsburg rain x 3.832 (PET as in the file);
+#   * sandy loam / sand / loam, 11 + 12 + 8 cm, synth_3 x 4.825 with a 0.5 cm ponding limit.
+# (The other AttributeError site, Layer.py:1606 -- the free-drainage front alone in the bottom layer -- was searched for with
+# the oracle over 280 000 random two- and three-layer columns and never came first: every column that got there had raised
+# ValueError at an earlier pow.)
+THIN = dict(PHIL, thickness=[4.0, 4.0, 4.0])
+CASES["crash_bottom_thin444_synth1"] = (run_case, dict(forcing="forcing_data_synth_1.txt", soil=THIN, pdm=0.0, subcycle_s=300,
+                                                       forcing_res_s=300, endtime_h=12.0))
+_rows = [_TEX[8], _TEX[0]]
+CASES["crash_bottom_two_layer_phil_600"] = (run_case, dict(
+    forcing=PH, soil=dict(alpha=[r[0] for r in _rows], n=[r[1] for r in _rows], ksat=[r[2] for r in _rows],
+                          theta_e=[r[3] for r in _rows], theta_r=[r[4] for r in _rows], thickness=[14.0, 26.0]),
+    pdm=0.0, subcycle_s=3600, forcing_res_s=3600, endtime_h=600.0, forcing_scale=3.832, scale_pet=False))
+_rows = [_TEX[3], _TEX[0], _TEX[7]]
+CASES["crash_bottom_three_layer_synth3"] = (run_case, dict(
+    forcing="forcing_data_synth_3.txt", soil=dict(alpha=[r[0] for r in _rows], n=[r[1] for r in _rows], ksat=[r[2] for r in _rows],
+                                                  theta_e=[r[3] for r in _rows], theta_r=[r[4] for r in _rows],
+                                                  thickness=[11.0, 12.0, 8.0]),
+    pdm=0.5, subcycle_s=300, forcing_res_s=300, endtime_h=12.0, forcing_scale=4.825, scale_pet=False))
+
+
 def _run(name):
     fn, kw = CASES[name]
     try:

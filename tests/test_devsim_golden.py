@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, golden_names
+from conftest import check_fault_kind, GOLDEN, golden_names
 
 
 def _rel(a, b, floor=1e-6):
@@ -59,6 +59,7 @@ def test_device_code_fp64_trajectory_vs_reference_golden(name, mode):
         f1 = g["forcing"][T:T + 1]
         eng.forward(np.repeat(f1[:, 0:1], 2, 1), np.repeat(f1[:, 1:2], 2, 1), series=())
         assert (eng.status != 0).all()
+        check_fault_kind(g, eng.status)
 
 
 @pytest.mark.parametrize("name", ["synth1_phil", "phil_hourly_3000", "four_layer_synth0_600", "two_layer_phil_600",
@@ -121,6 +122,7 @@ def test_device_code_mixed_precision_geff_vs_reference_golden(name):
         f1 = g["forcing"][T:T + 1]
         eng.forward(np.repeat(f1[:, 0:1], 2, 1), np.repeat(f1[:, 1:2], 2, 1), series=())
         assert (eng.status != 0).all()
+        check_fault_kind(g, eng.status)
 
 
 def test_mixed_precision_geff_leaf_accuracy():

@@ -11,7 +11,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN
+from conftest import check_fault_kind, GOLDEN
 from test_devsim_golden import MIXED_FLUX, MIXED_TOTAL, mixed_mode_check
 from test_gpu_parity import TRAJ, _engine, _forcing, _rel
 
@@ -46,6 +46,7 @@ def test_mixed_precision_trajectory_vs_reference_golden(name, mode):
         with pytest.raises(lg.LgarStatusError):
             eng.forward(pr1, pe1)
         assert bool((eng.status != 0).all())
+        check_fault_kind(g, eng.status.cpu().numpy())
 
 
 def test_mixed_geff_leaf_on_the_hardware():

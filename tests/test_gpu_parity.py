@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, golden_names
+from conftest import check_fault_kind, GOLDEN, golden_names
 
 pytestmark = pytest.mark.gpu
 
@@ -77,6 +77,7 @@ def test_fp64_trajectory_vs_reference_golden(name, mode):
         with pytest.raises(lg.LgarStatusError):
             eng.forward(pr1, pe1)
         assert bool((eng.status != 0).all())
+        check_fault_kind(g, eng.status.cpu().numpy())
 
 
 def test_config2_10k_replicated_phillipsburg_fp64():

@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, golden_names
+from conftest import GOLDEN, check_fault_kind, golden_names
 from oracle import lgar_oracle as O
 
 RTOL = 1e-9
@@ -45,6 +45,7 @@ def test_trajectory(name):
         # the reference raised at this step (e.g. ValueError: negative pow base); the oracle must flag the same step
         r2 = O.run(p, s, g["forcing"][T:T + 1, 0], g["forcing"][T:T + 1, 1])
         assert r2["status"] != 0, str(g["crash_msg"])
+        check_fault_kind(g, r2["status"])
 
 
 @pytest.mark.parametrize("name", ["phil_hourly_3000", "synth0_phil_1500", "synth1_phil", "bushland_hourly_1500",
