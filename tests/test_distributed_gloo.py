@@ -81,6 +81,39 @@ def test_two_rank_sharding_matches_single_process():
     assert basin1.sum() > 0
 
 
+@pytest.mark.timeout(300)
+def test_eight_rank_ragged_sharding_matches_single_process():
+    """configs[3]'s world size on the CPU (gloo): 8 ranks over a column count that 8 does not divide (shards of 6 and 5
+    columns), so the last ranks' bounds, the concatenation order and the [T] all-reduce are those an 8-GPU node will see."""
+    import socket
+    from lgar_py_amd.distributed import ShardedColumns
+    from lgar_py_amd.workloads import shard_bounds
+    N, world = 43, 8
+    P, pr, pe = _problem(N)
+    single = ShardedColumns(P, N, rank=0, world=1, engine_factory=_factory, dt_h=300.0 / 3600.0, ponded_depth_max=0.0)
+    out1, basin1 = single.run(pr, pe)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, N, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [(r[1], r[2]) for r in res] == [shard_bounds(N, world, k) for k in range(world)]
+    assert sorted(r[2] - r[1] for r in res) == [5] * 5 + [6] * 3
+    ro = np.concatenate([r[3] for r in res], axis=1)
+    assert np.array_equal(ro, out1["runoff"].numpy())
+    for r in res:
+        assert np.allclose(r[4], basin1.numpy(), rtol=1e-12, atol=1e-12)
+        assert np.array_equal(r[5], np.full(3, 36.0))          # 1 + 2 + ... + 8
+
+
 def _force_worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"

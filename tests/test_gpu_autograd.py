@@ -242,6 +242,71 @@ def test_ensemble_gradients_config5_shape():
             assert torch.allclose(Q[k].grad[:, 0], P[k].grad[:, c], rtol=1e-9, atol=1e-18), (c, k)
 
 
+@pytest.mark.timeout(900)
+def test_ensemble_gradients_config5_full_size():
+    """BASELINE configs[4] at its real size: 100 000 ensemble columns x 9 parameter directions = 900 000 lanes, which takes the
+    shared-trapezoid layout (tangent_share = 9) on the library's own threshold -- nothing is patched; a spy on
+    LgarEngine.tangent only records what autograd asked for.  Three members are checked against the single-column path (the
+    one the reference's own gradient fixtures pin), no tangent integration faults, and the fraction of the ensemble inside the
+    reference's domain of validity is the one bench.py reports."""
+    import lgar_py_amd as lg
+    from lgar_py_amd import autograd as AG
+    from lgar_py_amd import workloads as W
+    N = 100_000
+    E = W.ensemble_columns(N, seed=0)
+    f = W.synth1_forcing()
+    T = f.shape[0]
+    pr = torch.tensor(f[:, 0:1], device="cuda").expand(T, N).contiguous()
+    pe = torch.zeros_like(pr)
+    P = {k: torch.tensor(v, device="cuda") for k, v in E.items()}
+    for k in ("alpha", "n", "ksat"):
+        P[k].requires_grad_(True)
+    shares = []
+    real = lg.LgarEngine.tangent
+
+    def spy(self, *a, **kw):
+        shares.append((self.N, int(kw.get("share", 0))))
+        return real(self, *a, **kw)
+
+    lg.LgarEngine.tangent = spy
+    try:
+        st = []
+        runoff, _ = AG.lgar_series(P["alpha"], P["n"], P["ksat"], P["theta_e"], P["theta_r"], P["thickness"], pr, pe,
+                                   dt_h=300.0 / 3600.0, ponded_depth_max=0.0, dtype=torch.float64, check=False, status_out=st)
+        ok = st[0] == 0
+        loss = torch.mean(runoff[:, ok] ** 2)
+        loss.backward()
+    finally:
+        lg.LgarEngine.tangent = real
+    assert shares == [(9 * N, 9)], shares  # ONE launch, nine lanes per column sharing the trapezoid
+    assert 9 * N >= AG.SHARE_MIN_LANES
+    valid = float(ok.double().mean())
+    assert 0.955 <= valid <= 0.972, valid  # bench.py's configs4_autograd.valid_fraction (0.9636 on this seed)
+    assert len(st) == 2 and int((st[1] != 0).sum()) == 0  # tangent_faulted_fraction == 0
+    for k in ("alpha", "n", "ksat"):
+        gk = P[k].grad
+        assert gk.shape == (3, N) and bool(torch.isfinite(gk).all())
+        assert float(gk[:, ~ok].abs().sum()) == 0.0
+    assert float(P["ksat"].grad[0].abs().sum()) > 0
+    gmax = max(float(P[k].grad.abs().max()) for k in ("alpha", "n", "ksat"))
+    idx = torch.nonzero(ok).flatten()
+    for c in [int(idx[0]), int(idx[len(idx) // 2]), int(idx[-1])]:
+        Q = {k: P[k].detach()[:, c:c + 1].clone() for k in P}
+        for k in ("alpha", "n", "ksat"):
+            Q[k].requires_grad_(True)
+        r1, _ = AG.lgar_series(Q["alpha"], Q["n"], Q["ksat"], Q["theta_e"], Q["theta_r"], Q["thickness"],
+                               pr[:, c:c + 1].contiguous(), pe[:, c:c + 1].contiguous(), dt_h=300.0 / 3600.0,
+                               ponded_depth_max=0.0, dtype=torch.float64)
+        assert torch.equal(r1[:, 0], runoff[:, c].detach())
+        (torch.sum(r1 ** 2) / (T * int(ok.sum()))).backward()
+        for k in ("alpha", "n", "ksat"):
+            # shared vs plain trapezoid: the same sums in another order (DESIGN.md section 3); 1e-6 of the column's largest
+            # gradient entry is the bar of the reference's own gradient fixtures
+            scale = max(float(Q[kk].grad.abs().max()) for kk in ("alpha", "n", "ksat"))
+            assert float((Q[k].grad[:, 0] - P[k].grad[:, c]).abs().max()) <= 1e-6 * scale, (c, k)
+    assert gmax > 0
+
+
 def test_tangent_faults_are_reported_not_swallowed():
     """A column whose tangent integration faults (here: more than 32 fronts) has no gradient: parameter_vjp raises
     (check=True) or zeroes that column's entries and reports the status (check=False); clean columns are unaffected."""

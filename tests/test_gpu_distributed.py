@@ -82,6 +82,36 @@ def test_bench_self_spawns_its_ranks():
 
 
 @pytest.mark.timeout(900)
+def test_bench_under_the_drivers_launcher_with_four_ranks():
+    """The driver's own command line -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N ...` -- with N = 4 ranks sharing the one GPU (gloo rehearsal, 4 096 columns
+    per rank).  Four, not eight: the pool allows six processes on a card and this test process is one of them; the world-size-8
+    sharding and all-reduce run on the CPU (tests/test_distributed_gloo.py).  One JSON line from rank 0, n_gpus 4, the
+    collective named, four ranks' worth of work, every rank on a device that exists."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, LGAR_DIST_BACKEND="gloo", LGAR_CPU_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LGAR_FORCE_DIST", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2",
+                        "--warmup", "1", "--columns", "4096"], capture_output=True, text=True, env=env, timeout=800)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 4 and d["scaling"] == "weak" and d["config"]["columns_per_gpu"] == 4096
+    assert "gloo all-reduce" in d["config"]["collective"] and "group of 4" in d["config"]["collective"]
+    assert d["config"]["parallelism"] == "columns sharded x4" and d["faulted_columns"] == 0
+    units = 4 * 4096 * 144 * 2
+    assert abs(d["value"] - units / (d["ms_per_step"] * 2e-3)) <= 1e-6 * d["value"]
+    assert "sub_records" not in d and "cpu_baseline" not in d  # N > 1: rank 0 prints the headline only
+
+
+@pytest.mark.timeout(900)
 def test_rccl_group_of_one_runs_the_real_all_reduce(tmp_path):
     """configs[3]'s exchange on what one GPU can host: the worker joins an RCCL ("nccl") process group of world size 1 and,
     with LGAR_FORCE_DIST=1, distributed.basin_runoff runs dist.all_reduce on the DEVICE [T] vector (no host hop).  The result

@@ -155,6 +155,52 @@ def test_streamed_run_equals_single_shot():
     assert torch.allclose(basin, full["runoff"].sum(1), rtol=1e-12, atol=1e-12)
 
 
+def test_streamed_per_column_forcing_from_a_mapped_file_equals_single_shot(tmp_path):
+    """pipeline.run_streamed_columns: [T, N] forcing with N distinct columns in a memory-mapped file -> pinned double buffer
+    -> HBM on a side stream, chunk by chunk == one launch over the whole resident [T, N] forcing, bit for bit; per-column PET
+    from a second file, a basin PET series, and an fp32 file feeding an fp64 engine (converted on the device)."""
+    import lgar_py_amd as lg
+    from lgar_py_amd import workloads as W
+    from lgar_py_amd.pipeline import open_forcing_file, run_streamed_columns, write_forcing_file
+    g = np.load(os.path.join(GOLDEN, "phil_hourly_3000.npz"))
+    N, T = 517, 700
+    rng = np.random.default_rng(5)
+    P = W.perturbed_columns(N, seed=31)
+    kw = dict(dt_h=1.0, ponded_depth_max=2.0, dtype=torch.float64)
+    x = g["forcing"][:T]
+    pr = x[:, 0:1] * rng.uniform(0.5, 2.5, (T, N))   # every column its own series
+    pe = x[:, 1:2] * rng.uniform(0.8, 1.2, (T, N))
+    mk = lambda: lg.LgarEngine(P["alpha"], P["n"], P["ksat"], P["theta_e"], P["theta_r"], P["thickness"], **kw)
+    a = mk()
+    full = a.forward(torch.tensor(pr), torch.tensor(pe), series=("runoff", "AET"), check=False)
+    fp = open_forcing_file(write_forcing_file(str(tmp_path / "precip.npy"), pr))
+    fe = open_forcing_file(write_forcing_file(str(tmp_path / "pet.npy"), pe))
+    assert isinstance(fp, np.memmap) and fp.shape == (T, N)
+    b = mk()
+    st = {}
+    got = run_streamed_columns(b, fp, fe, chunk=97, series=("runoff", "AET"), reduce_basin=False, check=False, stats=st)
+    for nm in ("runoff", "AET"):
+        assert torch.equal(got[nm], full[nm]), nm
+    assert torch.equal(a.theta, b.theta) and torch.equal(a.status, b.status)
+    assert st["bytes_host_to_device"] == 2 * T * N * 8 and st["chunks"] == 8 and st["host_to_device_GBps"] > 0
+    # basin sums, basin PET series
+    c = mk()
+    full2 = c.forward(torch.tensor(pr), torch.tensor(np.repeat(x[:, 1:2], N, 1)), series=("runoff",), check=False)
+    d = mk()
+    basin = run_streamed_columns(d, fp, x[:, 1], chunk=256, series=("runoff",), check=False)["runoff"]
+    assert basin.shape == (T,) and torch.allclose(basin, full2["runoff"].sum(1), rtol=1e-12, atol=1e-12)
+    assert torch.equal(c.theta, d.theta)
+    # an fp32 file into the fp64 engine: the same as uploading the rounded values
+    f32 = open_forcing_file(write_forcing_file(str(tmp_path / "precip32.npy"), pr.astype(np.float32)))
+    e, f = mk(), mk()
+    want = e.forward(torch.tensor(pr.astype(np.float32).astype(np.float64)), torch.zeros(T, N, dtype=torch.float64),
+                     series=("runoff",), check=False)
+    got32 = run_streamed_columns(f, f32, None, chunk=300, series=("runoff",), reduce_basin=False, check=False)
+    assert torch.equal(got32["runoff"], want["runoff"])
+    with pytest.raises(ValueError):
+        run_streamed_columns(mk(), pr[:, :5], None)
+
+
 def test_in_kernel_basin_aggregation():
     """LgarStepOut.basin: per-step basin sums reduced in the kernel epilogue (wave reduction + fp64 atomics) equal the
     column sums of the per-step series, with and without weights, including a ragged tail wave."""

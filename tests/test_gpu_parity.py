@@ -395,6 +395,45 @@ def test_wide_parameter_ensemble_vs_oracle_fp64():
         assert np.abs(got[:, ok] - ro[:, ok]).max() <= 1e-6 * max(1.0, np.abs(ro[:, ok]).max()), mode
 
 
+@pytest.mark.timeout(900)
+def test_wide_parameter_sweep_65536_columns_vs_oracle():
+    """tools/parity_sweep.py's wide shape in the driver's suite: 65 536 columns drawn from configs[4]'s parameter ranges, every
+    column against the oracle in the fast and the literal mode.  Saturating top layers make the reference's own decisions hinge on
+    the last bit of pow there, so a few columns in 10^4 take another branch than the oracle under any
+    other libm: the count is bounded (<= 0.05 % fault-flag flips, <= 0.05 % of the jointly valid columns off by more than
+    1e-6; observed r03: 0.016-0.026 % in total), everything else agrees to 1e-6.  The mixed-precision mode is held to its own,
+    wider bar on this ill-conditioned ensemble (<= 0.4 % flips)."""
+    import lgar_py_amd as lg
+    from lgar_py_amd import workloads as W
+    from oracle import lgar_oracle as O
+    N = 65536
+    E = W.ensemble_columns(N, seed=300)
+    f = W.synth1_forcing()
+    pr = np.repeat(f[:, 0:1], N, 1)
+    pe = np.zeros_like(pr)
+    ro, pc, acc, st = O.run_columns(E["alpha"], E["n"], E["ksat"], E["theta_e"], E["theta_r"], E["thickness"], pr, pe,
+                                    pdm=0.0, dt_h=300.0 / 3600.0)
+    scale = max(1.0, np.abs(ro).max())
+    report = {}
+    for mode in (1, 0, "mixed"):
+        mk = dict(search_mode=1, geff_precision="f32") if mode == "mixed" else dict(search_mode=mode)
+        eng = lg.LgarEngine(E["alpha"], E["n"], E["ksat"], E["theta_e"], E["theta_r"], E["thickness"], dt_h=300.0 / 3600.0,
+                            ponded_depth_max=0.0, dtype=torch.float64, **mk)
+        out = eng.forward(torch.tensor(pr), torch.tensor(pe), series=("runoff",), check=False)
+        gst = eng.status.cpu().numpy() & 0x7f
+        flips = int(((st != 0) != (gst != 0)).sum())
+        both = (st == 0) & (gst == 0)
+        col_err = np.abs(out["runoff"].cpu().numpy() - ro).max(0) / scale
+        off = int((col_err[both] > 1e-6).sum())
+        report[mode] = (flips, off)
+        assert both.mean() > 0.9
+        if mode == "mixed":
+            assert flips <= 0.004 * N and off <= 0.02 * N, report
+        else:
+            assert flips <= 0.0005 * N and off <= 0.0005 * N, report
+    print("wide sweep (flag flips, columns off by > 1e-6):", report)
+
+
 def test_percolating_bottom_boundary_matches_oracle():
     """bottom_mode=1 (LGAR-C intent; the reference crashes there, so this is oracle-vs-kernel only): fronts that
     reach the domain bottom leave as percolation and the column keeps integrating."""
