@@ -41,7 +41,7 @@ template <typename S> using real_t = typename Real<S>::type;
 
 __device__ __forceinline__ double val(double x) { return x; }
 __device__ __forceinline__ float val(float x) { return x; }
-__device__ __forceinline__ double pw(double x, double y) { return fast_pow(x, y); }  // lgar_math.hpp, ~1e-14 relative
+__device__ __forceinline__ double pw(double x, double y) { return fast_pow<false>(x, y); }  // lgar_math.hpp, ~1e-14 relative
 // fp32: v_log_f32 / v_exp_f32 (quarter-rate transcendentals), ~2-3 ulp for the exponents used here
 // log2 / exp2 (fused Geff node, dual-number pow)
 #ifndef LGAR_DEVSIM
@@ -70,6 +70,19 @@ template <bool EX> __device__ __forceinline__ double pwx(double x, double y) {
   return pw(x, y);
 }
 template <bool EX> __device__ __forceinline__ float pwx(float x, float y) { return pw(x, y); }
+// pow by arithmetic policy POL (see dv): 1 = the library's, 3 = the lean pow with pairwise-combined polynomials (lgar_math.hpp,
+// ESTRIN), anything else the lean pow
+template <int POL> __device__ __forceinline__ double pwp(double x, double y) {
+  if constexpr (POL == 1) return pow(x, y);
+  if constexpr (POL == 3) return fast_pow<true>(x, y);
+  return fast_pow<false>(x, y);
+}
+template <int POL> __device__ __forceinline__ float pwp(float x, float y) { return pw(x, y); }
+// ... for any scalar type of the column physics: plain reals by pwp, dual numbers by their own pwx (lgar_dual.hpp)
+template <typename S, int POL> __device__ __forceinline__ S pwq(const S &x, const S &y) {
+  if constexpr (sizeof(S) == sizeof(real_t<S>)) return pwp<POL>(x, y);
+  else return pwx<POL == 1>(x, y);
+}
 
 // Arithmetic policy of the leaf functions and the column physics (template parameter POL):
 //   0  lean pow (lgar_math.hpp), IEEE division                        -- fp64 fast mode, dual numbers
@@ -86,14 +99,35 @@ template <int POL> __device__ __forceinline__ float dv(float a, float b) {
   if constexpr (POL == 2) return a * rcp32(b);
   return a / b;
 }
-template <int POL> __device__ __forceinline__ double dv(double a, double b) { return a / b; }
-__device__ __forceinline__ double lg2(double x) { return fast_log2(x); }
-__device__ __forceinline__ double ex2(double x) { return fast_exp2(x); }
+// POL 0 in double precision (fast modes): a / b as a * (1 / b) from v_rcp_f64, one Newton step on the reciprocal and one
+// correction of the quotient -- six instructions, within an ulp of the IEEE quotient, against the ~14 of the correctly rounded
+// divide (v_div_scale / v_div_fmas / v_div_fixup); a column step takes ~25 of them, each on its wave's critical path.  The
+// divisors of the column physics are finite and non-zero (depths, theta differences that were tested > 0, 1 + (alpha psi)^n).
+// Se = (theta - theta_r) / (theta_e - theta_r) keeps the IEEE divide (se_from_theta: x / x must be exactly 1).
+#ifndef LGAR_DEVSIM
+__device__ __forceinline__ double lean_div(double a, double b) {
+  double r = __builtin_amdgcn_rcp(b);
+  r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+  const double q = a * r;
+  return __builtin_fma(__builtin_fma(-b, q, a), r, q);
+}
+#else
+__device__ __forceinline__ double lean_div(double a, double b) { return a / b; }
+#endif
+template <int POL> __device__ __forceinline__ double dv(double a, double b) {
+  if constexpr (POL == 0 || POL == 3) return lean_div(a, b);
+  return a / b;
+}
+__device__ __forceinline__ double lg2(double x) { return fast_log2<false>(x); }
+__device__ __forceinline__ double ex2(double x) { return fast_exp2<false>(x); }
+// (the mixed-precision trapezoid's own double-precision logarithms and exponentials: see fast_pow on ESTRIN)
+__device__ __forceinline__ double lg2e(double x) { return fast_log2<true>(x); }
+__device__ __forceinline__ double ex2e(double x) { return fast_exp2<true>(x); }
 // log2 / exp2 of arguments known to be positive / not NaN (the interior of the Geff trapezoid): no special-case selects
 __device__ __forceinline__ float lg2p(float x) { return lg2(x); }
 __device__ __forceinline__ float ex2p(float x) { return ex2(x); }
-__device__ __forceinline__ double lg2p(double x) { return fast_log2_core(x); }
-__device__ __forceinline__ double ex2p(double x) { return fast_exp2_core<false>(x); }
+__device__ __forceinline__ double lg2p(double x) { return fast_log2_core<false>(x); }
+__device__ __forceinline__ double ex2p(double x) { return fast_exp2_core<false, false>(x); }
 __device__ __forceinline__ double sq(double x) { return sqrt(x); }
 __device__ __forceinline__ double ab(double x) { return fabs(x); }
 __device__ __forceinline__ float ab(float x) { return fabsf(x); }
@@ -162,9 +196,9 @@ template <typename S, int NL> __device__ __forceinline__ LayerK<S> pick(const Co
   l.alpha = sel<S, NL>(P.alpha, k);
   l.n = sel<S, NL>(P.n, k);
   l.m = sel<S, NL>(P.m, k);
+  l.ksat = sel<S, NL>(P.ksat, k);
   l.inv_m = sel<S, NL>(P.inv_m, k);
   l.inv_n = sel<S, NL>(P.inv_n, k);
-  l.ksat = sel<S, NL>(P.ksat, k);
   l.te = sel<S, NL>(P.te, k);
   l.tr = sel<S, NL>(P.tr, k);
   return l;
@@ -182,17 +216,15 @@ template <typename S, int NL> __device__ __forceinline__ LayerK<S> pick_static(c
 // calc_theta_from_h, utils.py:35-51
 template <typename S, int POL = 0> __device__ __forceinline__ S theta_from_h(const LayerK<S> &l, S h) {
   using R = real_t<S>;
-  constexpr bool EX = POL == 1;
-  S ap = pwx<EX>(l.alpha * h, l.n);
-  S op = pwx<EX>(R(1.0) + ap, l.m);
+  S ap = pwq<S, POL>(l.alpha * h, l.n);
+  S op = pwq<S, POL>(R(1.0) + ap, l.m);
   return (dv<POL>(S(R(1.0)), op) * (l.te - l.tr)) + l.tr;
 }
 // ... also handing out (alpha h)^n, the quantity that says how close to saturation the head is
 template <typename S, int POL = 0> __device__ __forceinline__ S theta_from_h_ap(const LayerK<S> &l, S h, S &ap) {
   using R = real_t<S>;
-  constexpr bool EX = POL == 1;
-  ap = pwx<EX>(l.alpha * h, l.n);
-  S op = pwx<EX>(R(1.0) + ap, l.m);
+  ap = pwq<S, POL>(l.alpha * h, l.n);
+  S op = pwq<S, POL>(R(1.0) + ap, l.m);
   return (dv<POL>(S(R(1.0)), op) * (l.te - l.tr)) + l.tr;
 }
 // calc_se_from_theta, utils.py:102-112
@@ -202,30 +234,27 @@ template <typename S> __device__ __forceinline__ S se_from_theta(const LayerK<S>
 // calc_se_from_h, utils.py:115-131 (exactly 1 for |h| < 0.1)
 template <typename S, int POL = 0> __device__ __forceinline__ S se_from_h(const LayerK<S> &l, S h) {
   using R = real_t<S>;
-  constexpr bool EX = POL == 1;
   if (ab(val(h)) < R(1.0e-01)) return S(R(1.0));
-  S is = pwx<EX>(l.alpha * h, l.n);
-  return dv<POL>(S(R(1.0)), pwx<EX>(R(1.0) + is, l.m));
+  S is = pwq<S, POL>(l.alpha * h, l.n);
+  return dv<POL>(S(R(1.0)), pwq<S, POL>(R(1.0) + is, l.m));
 }
 // calc_k_from_se, utils.py:134-156; torch.isclose(base, 0, rtol=1e-12) => |base| <= 1e-8 (default atol)
 template <typename S, int POL = 0> __device__ __forceinline__ S k_from_se(const LayerK<S> &l, S se) {
   using R = real_t<S>;
-  constexpr bool EX = POL == 1;
-  S sp = pwx<EX>(se, l.inv_m);
+  S sp = pwq<S, POL>(se, l.inv_m);
   S base = R(1.0) - sp;
   if (ab(val(base)) <= R(1e-8)) base = base + R(1e-12);
-  S op = pwx<EX>(base, l.m);
+  S op = pwq<S, POL>(base, l.m);
   S t = R(1.0) - op;
   return l.ksat * sq(se) * (t * t);
 }
 // calc_h_from_se, utils.py:159-174
 template <typename S, int POL = 0> __device__ __forceinline__ S h_from_se(const LayerK<S> &l, S se) {
   using R = real_t<S>;
-  constexpr bool EX = POL == 1;
-  S sp = pwx<EX>(se, -l.inv_m);
+  S sp = pwq<S, POL>(se, -l.inv_m);
   S base = sp - R(1.0);
   if (ab(val(base)) <= R(1e-8)) base = base + R(1e-12);
-  S op = pwx<EX>(base, l.inv_n);
+  S op = pwq<S, POL>(base, l.inv_n);
   return dv<POL>(S(R(1.0)), l.alpha) * op;
 }
 // calc_geff, models/physics/lgar/green_ampt.py:45-84: nint-interval trapezoid of K(h) dh / Ksat.
@@ -618,38 +647,28 @@ template <> __device__ __forceinline__ double geff<double>(const LayerK<double> 
 // logarithm of 1e-12; a base in (0, 1e-8] (Se within 1e-8 of 1 but not 1) takes its own logarithm on a wave-uniform branch.
 #define LGAR_LOG2_1EM12 -39.863137138648355  // log2(1e-12): the nudged base at Se == 1
 __device__ __forceinline__ void mixed_end(const LayerK<double> &l, double se, double &h, double &kr) {
-  const double q = lg2(se) * l.inv_m;
-  const double C = ex2(q);  // Se^(1/m)
+  const double q = lg2e(se) * l.inv_m;
+  const double C = ex2e(q);  // Se^(1/m)
   const double omc = 1.0 - C;
   const bool k_nudged = fabs(omc) <= 1e-8;
   const double bk = k_nudged ? omc + 1e-12 : omc;
-  const double u = (omc == 0.0) ? LGAR_LOG2_1EM12 : lg2(bk);  // (the constant: the saturated end below takes the same value)
-  const double t = 1.0 - ex2(l.m * u);
+  const double u = (omc == 0.0) ? LGAR_LOG2_1EM12 : lg2e(bk);  // (the constant: the saturated end below takes the same value)
+  const double t = 1.0 - ex2e(l.m * u);
   kr = sqrt(se) * (t * t);
   const double bh = omc / C;  // Se^(-1/m) - 1
   const bool h_nudged = fabs(bh) <= 1e-8;
   double lbh = (omc == 0.0) ? u : u - q;  // log2 of the (nudged) base of h
   if (any_lane((k_nudged || h_nudged) && omc != 0.0) != 0ull) {
-    const double own = lg2(h_nudged ? bh + 1e-12 : bh);
+    const double own = lg2e(h_nudged ? bh + 1e-12 : bh);
     lbh = ((k_nudged || h_nudged) && omc != 0.0) ? own : lbh;
   }
-  h = (1.0 / l.alpha) * ex2(lbh * l.inv_n);
+  h = (1.0 / l.alpha) * ex2e(lbh * l.inv_n);
 }
-__device__ __forceinline__ double geff_mixed(const LayerK<double> &l, double theta1, double theta2, int nint) {
-  const double se_i = se_from_theta(l, theta1);
-  const double se_f = se_from_theta(l, theta2);
-  // K_r at Se == 1 (the 1e-12 nudge of calc_k_from_se): (1 - (1e-12)^m)^2
-  const double tsat = 1.0 - ex2p(l.m * LGAR_LOG2_1EM12);
-  const double ksat1 = tsat * tsat;
+// The interior of the mixed-precision trapezoid and its closing formula, given both heads, K_r of both end nodes and K_r at
+// Se == 1 (see geff_mixed / geff_mixed_heads for where they come from).
+__device__ __forceinline__ double geff_mixed_core(const LayerK<double> &l, double h_i, double h_f, double k0, double kn_own, double ksat1,
+                                                  int nint) {
   const float ksat1f = (float)ksat1;
-  double h_i, h_f, k0, kn_own;
-  mixed_end(l, se_i, h_i, k0);
-  if (any_lane(se_f != 1.0) != 0ull) {
-    mixed_end(l, se_f, h_f, kn_own);
-  } else {  // every lane's wet end is saturated (theta_2 == theta_e: new fronts, infiltration): what mixed_end returns for Se == 1
-    h_f = (1.0 / l.alpha) * ex2(LGAR_LOG2_1EM12 * l.inv_n);
-    kn_own = ksat1;
-  }
   const double dh = (h_f - h_i) / double(nint);
   const double x0 = l.alpha * h_i, dx = l.alpha * dh, xcut = 0.1 * l.alpha;
   // exponents as fp32 pairs
@@ -676,8 +695,13 @@ __device__ __forceinline__ double geff_mixed(const LayerK<double> &l, double the
   const f32x2 c4_2 = {0.00961812911f, 0.00961812911f}, c5_2 = {0.00133335581f, 0.00133335581f};
   const f32x2 mm2 = {mmf, mmf}, mml2 = {mmf_lo, mmf_lo}, ilog2 = {1.44269504f, 1.44269504f}, two_ilog2 = {2.88539008f, 2.88539008f};
   const f32x2 half2 = {0.5f, 0.5f};
-  // one node pair: sqrt(Se) and (1 - P Se)^2 of the nodes at X.x, X.y
-#define LGAR_GEFFM_PAIR(X, SR, TT)                                                          \
+  // one node pair: sqrt(Se) and (1 - P Se)^2 of the nodes at X.x, X.y.
+  // KIND says what is KNOWN about the pair (a compile-time literal; it never changes a result, only which of two values that
+  // the general form computes and then discards is not computed at all):
+  //   0  nothing: t = 1 - 2^E and its series are both formed and chosen between by 2^E > 7/8 (the general form);
+  //   1  2^E > 7/8 for certain (dry nodes): the series only -- no 2^E, no select, and 1 + r < 2 needs no clamp;
+  //   2  2^E <= 7/8 for certain (wet nodes): the difference only -- no series, no select.
+#define LGAR_GEFFM_PAIR(X, SR, TT, KIND)                                                    \
   {                                                                                         \
     /* log2 a = n log2 x;  r = 1/a;  L = log2(1 + r) from c = fl(1 + r), compensated for the rounding of the sum  */ \
     f32x2 lg, r, Lc;                                                                        \
@@ -689,7 +713,7 @@ __device__ __forceinline__ double geff_mixed(const LayerK<double> &l, double the
     Lc.x = lg2(c.x); Lc.y = lg2(c.y);                                                       \
     /* (2 - c) / ln 2 ~ 1 / (c ln 2) where the correction matters (c near 1); nothing for c >= 2 */ \
     f32x2 ic = __builtin_elementwise_fma(-ilog2, c, two_ilog2);                             \
-    ic.x = fmaxf(ic.x, 0.0f); ic.y = fmaxf(ic.y, 0.0f);                                     \
+    if ((KIND) != 1) { ic.x = fmaxf(ic.x, 0.0f); ic.y = fmaxf(ic.y, 0.0f); }                \
     const f32x2 L = __builtin_elementwise_fma(rho, ic, Lc);                                 \
     /* E = -m L = log2 (a/(1+a))^m;  sqrt(Se) = (1 + a)^(-m/2) = 2^(-m/2 (log2 a + L)) = 2^(-m/2 log2 a + E/2) */ \
     const f32x2 E = __builtin_elementwise_fma(mm2, L, mml2 * L);                            \
@@ -697,16 +721,29 @@ __device__ __forceinline__ double geff_mixed(const LayerK<double> &l, double the
     (SR).x = ex2(e1.x); (SR).y = ex2(e1.y);                                                 \
     /* t = 1 - 2^E.  Dry nodes have 2^E -> 1: there t = -expm1(E ln 2) by its series in E (5 terms for 2^E > 7/8), not by \
        the cancelling difference */                                                         \
-    f32x2 w;                                                                                \
-    w.x = ex2(E.x); w.y = ex2(E.y);                                                         \
-    f32x2 p = __builtin_elementwise_fma(c5_2, E, c4_2);                                     \
-    p = __builtin_elementwise_fma(p, E, c3_2);                                              \
-    p = __builtin_elementwise_fma(p, E, c2_2);                                              \
-    p = __builtin_elementwise_fma(p, E, ln2_2);                                             \
-    const f32x2 ts = -E * p;                                                                \
-    f32x2 t = one2 - w;                                                                     \
-    t.x = (w.x > 0.875f) ? ts.x : t.x;                                                      \
-    t.y = (w.y > 0.875f) ? ts.y : t.y;                                                      \
+    f32x2 t;                                                                                \
+    if ((KIND) == 1) {                                                                      \
+      f32x2 p = __builtin_elementwise_fma(c5_2, E, c4_2);                                   \
+      p = __builtin_elementwise_fma(p, E, c3_2);                                            \
+      p = __builtin_elementwise_fma(p, E, c2_2);                                            \
+      p = __builtin_elementwise_fma(p, E, ln2_2);                                           \
+      t = -E * p;                                                                           \
+    } else if ((KIND) == 2) {                                                               \
+      f32x2 w;                                                                              \
+      w.x = ex2(E.x); w.y = ex2(E.y);                                                       \
+      t = one2 - w;                                                                         \
+    } else {                                                                                \
+      f32x2 w;                                                                              \
+      w.x = ex2(E.x); w.y = ex2(E.y);                                                       \
+      f32x2 p = __builtin_elementwise_fma(c5_2, E, c4_2);                                   \
+      p = __builtin_elementwise_fma(p, E, c3_2);                                            \
+      p = __builtin_elementwise_fma(p, E, c2_2);                                            \
+      p = __builtin_elementwise_fma(p, E, ln2_2);                                           \
+      const f32x2 ts = -E * p;                                                              \
+      t = one2 - w;                                                                         \
+      t.x = (w.x > 0.875f) ? ts.x : t.x;                                                    \
+      t.y = (w.y > 0.875f) ? ts.y : t.y;                                                    \
+    }                                                                                       \
     (TT) = t * t;                                                                           \
   }
   // node abscissae x_j = x0 + j dx in fp32 from hi + lo pairs of x0 and dx: t = fma(j, dx_hi, x0_hi) is rounded once (and is
@@ -724,39 +761,112 @@ __device__ __forceinline__ double geff_mixed(const LayerK<double> &l, double the
   // halves) and the group's sum goes into the double-precision accumulator.  Groups whose nodes may fall under the
   // |h| < 0.1 cut (wave-uniform test) take K_r = ksat1 there: the same operations otherwise, so a column's result does not
   // depend on its wavefront
-#define LGAR_GEFFM_GROUP(CUT)                                                               \
+  // The two pairs of a group go through the node formula in LOCKSTEP, statement by statement: every packed operation of a
+  // node depends on the one before it, and a dependent operation cannot issue in the slot after its producer (the compiler
+  // fills those slots with s_nop when it has nothing else) -- a wave that walks one chain after the other spends half its issue
+  // slots waiting.  Same operations on the same operands as LGAR_GEFFM_PAIR, pair by pair: the same values bit for bit.
+#define LGAR_GEFFM_GROUP(CUT, KIND)                                                         \
   {                                                                                         \
-    const f32x2 xa = __builtin_elementwise_fma(ja, dxh2, x0h2) + __builtin_elementwise_fma(ja, dxl2, x0l2); \
-    const f32x2 xb = __builtin_elementwise_fma(jb, dxh2, x0h2) + __builtin_elementwise_fma(jb, dxl2, x0l2); \
-    f32x2 sa, ta, sb, tb;                                                                   \
-    LGAR_GEFFM_PAIR(xa, sa, ta)                                                             \
+    const f32x2 xha = __builtin_elementwise_fma(ja, dxh2, x0h2), xhb = __builtin_elementwise_fma(jb, dxh2, x0h2); \
+    const f32x2 xla = __builtin_elementwise_fma(ja, dxl2, x0l2), xlb = __builtin_elementwise_fma(jb, dxl2, x0l2); \
+    const f32x2 xa = xha + xla, xb = xhb + xlb;                                             \
+    f32x2 lga, lgb, ra, rb, Lca, Lcb, sa, sb, ta, tb;                                       \
+    lga.x = lg2(xa.x); lgb.x = lg2(xb.x); lga.y = lg2(xa.y); lgb.y = lg2(xb.y);             \
+    const f32x2 ua = nl2 * lga, ub = nl2 * lgb;                                             \
+    const f32x2 laa = __builtin_elementwise_fma(n2, lga, ua), lab = __builtin_elementwise_fma(n2, lgb, ub); \
+    ra.x = ex2(-laa.x); rb.x = ex2(-lab.x); ra.y = ex2(-laa.y); rb.y = ex2(-lab.y);         \
+    const f32x2 ca = one2 + ra, cb = one2 + rb;                                             \
+    Lca.x = lg2(ca.x); Lcb.x = lg2(cb.x); Lca.y = lg2(ca.y); Lcb.y = lg2(cb.y);             \
+    const f32x2 da = ca - one2, db = cb - one2;                                             \
+    f32x2 ica = __builtin_elementwise_fma(-ilog2, ca, two_ilog2), icb = __builtin_elementwise_fma(-ilog2, cb, two_ilog2); \
+    const f32x2 rhoa = ra - da, rhob = rb - db;                                             \
+    if ((KIND) != 1) {                                                                      \
+      ica.x = fmaxf(ica.x, 0.0f); icb.x = fmaxf(icb.x, 0.0f); ica.y = fmaxf(ica.y, 0.0f); icb.y = fmaxf(icb.y, 0.0f); \
+    }                                                                                       \
+    const f32x2 La = __builtin_elementwise_fma(rhoa, ica, Lca), Lb = __builtin_elementwise_fma(rhob, icb, Lcb); \
+    const f32x2 va = mml2 * La, vb = mml2 * Lb;                                             \
+    const f32x2 Ea = __builtin_elementwise_fma(mm2, La, va), Eb = __builtin_elementwise_fma(mm2, Lb, vb); \
+    const f32x2 ha = half2 * Ea, hb = half2 * Eb;                                           \
+    const f32x2 ga = __builtin_elementwise_fma(hml2, laa, ha), gb = __builtin_elementwise_fma(hml2, lab, hb); \
+    const f32x2 e1a = __builtin_elementwise_fma(hm2, laa, ga), e1b = __builtin_elementwise_fma(hm2, lab, gb); \
+    sa.x = ex2(e1a.x); sb.x = ex2(e1b.x); sa.y = ex2(e1a.y); sb.y = ex2(e1b.y);             \
+    f32x2 wa, wb, pa, pb, t1a, t1b;                                                         \
+    if ((KIND) != 1) {                                                                      \
+      wa.x = ex2(Ea.x); wb.x = ex2(Eb.x); wa.y = ex2(Ea.y); wb.y = ex2(Eb.y);               \
+      t1a = one2 - wa; t1b = one2 - wb;                                                     \
+    }                                                                                       \
+    if ((KIND) != 2) {                                                                      \
+      pa = __builtin_elementwise_fma(c5_2, Ea, c4_2); pb = __builtin_elementwise_fma(c5_2, Eb, c4_2); \
+      pa = __builtin_elementwise_fma(pa, Ea, c3_2); pb = __builtin_elementwise_fma(pb, Eb, c3_2); \
+      pa = __builtin_elementwise_fma(pa, Ea, c2_2); pb = __builtin_elementwise_fma(pb, Eb, c2_2); \
+      pa = __builtin_elementwise_fma(pa, Ea, ln2_2); pb = __builtin_elementwise_fma(pb, Eb, ln2_2); \
+      pa = -Ea * pa; pb = -Eb * pb;                                                         \
+    }                                                                                       \
+    if ((KIND) == 1) { t1a = pa; t1b = pb; }                                                \
+    if ((KIND) == 0) {                                                                      \
+      t1a.x = (wa.x > 0.875f) ? pa.x : t1a.x; t1b.x = (wb.x > 0.875f) ? pb.x : t1b.x;       \
+      t1a.y = (wa.y > 0.875f) ? pa.y : t1a.y; t1b.y = (wb.y > 0.875f) ? pb.y : t1b.y;       \
+    }                                                                                       \
+    ta = t1a * t1a; tb = t1b * t1b;                                                         \
     if (CUT) {                                                                              \
-      sa.x = (xa.x < xcutf) ? ksat1f : sa.x;                                                \
-      ta.x = (xa.x < xcutf) ? 1.0f : ta.x;                                                  \
-      sa.y = (xa.y < xcutf) ? ksat1f : sa.y;                                                \
-      ta.y = (xa.y < xcutf) ? 1.0f : ta.y;                                                  \
+      sa.x = (xa.x < xcutf) ? ksat1f : sa.x; sb.x = (xb.x < xcutf) ? ksat1f : sb.x;         \
+      ta.x = (xa.x < xcutf) ? 1.0f : ta.x; tb.x = (xb.x < xcutf) ? 1.0f : tb.x;             \
+      sa.y = (xa.y < xcutf) ? ksat1f : sa.y; sb.y = (xb.y < xcutf) ? ksat1f : sb.y;         \
+      ta.y = (xa.y < xcutf) ? 1.0f : ta.y; tb.y = (xb.y < xcutf) ? 1.0f : tb.y;             \
     }                                                                                       \
     const f32x2 ka = sa * ta;                                                               \
-    LGAR_GEFFM_PAIR(xb, sb, tb)                                                             \
-    if (CUT) {                                                                              \
-      sb.x = (xb.x < xcutf) ? ksat1f : sb.x;                                                \
-      tb.x = (xb.x < xcutf) ? 1.0f : tb.x;                                                  \
-      sb.y = (xb.y < xcutf) ? ksat1f : sb.y;                                                \
-      tb.y = (xb.y < xcutf) ? 1.0f : tb.y;                                                  \
-    }                                                                                       \
     const f32x2 kb = __builtin_elementwise_fma(sb, tb, ka);                                 \
     sum = sum + (double)(kb.x + kb.y);                                                      \
   }
-  for (; it + 1 < safe_pairs; it += 2, ja = ja + four2, jb = jb + four2) LGAR_GEFFM_GROUP(false)
-  for (; it + 1 < pairs; it += 2, ja = ja + four2, jb = jb + four2) LGAR_GEFFM_GROUP(true)
+  // Which of the two forms of t a node takes depends on 2^E > 7/8, and E rises monotonically with x = alpha h: the series
+  // region is a PREFIX of the nodes (x > x_thr, the dry end), the difference region a suffix.  x_thr -- (1 + x^-n)^-m = 7/8 --
+  // is a function of the layer's n alone; a node further than 1e-4 (relative) from it is decided whatever the rounding of
+  // its E (1e-4 in x moves E by >= 1e-5, the computed E and 2^E are good to ~3e-7).  Each lane counts the leading nodes that
+  // are series for certain and the first node from which all are differences for certain; the wavefront runs the series-only
+  // form up to the smallest of the former, the difference-only form from the largest of the latter, the general form in
+  // between -- every node gets exactly the value the general form alone would give it (bit for bit: tests/devsim).
+  int ser_pairs = 0, dir_pair = pairs + 1;  // (a reversed or empty range, or NaN: the general form throughout)
+  if (dx < 0.0) {
+    const float x_thr = pw(pw(8.0f / 7.0f, (float)l.inv_m) - 1.0f, -(float)l.inv_n);
+    const double js_f = (x0 - (double)(x_thr * 1.0001f)) / -dx - 1.0;  // nodes 1 .. js: x_j > x_thr (1 + 1e-4)
+    const int js = (js_f > 0.0) ? ((js_f < double(M)) ? int(js_f) : M) : 0;
+    ser_pairs = js >> 1;                                               // pairs 0 .. ser_pairs - 1 hold only such nodes
+    const double jd_f = (x0 - (double)(x_thr * 0.9999f)) / -dx + 2.0;  // nodes jd ..: x_j < x_thr (1 - 1e-4)
+    const int jd = !(jd_f < double(M + 2)) ? M + 2 : ((jd_f > 0.0) ? int(jd_f) : 0);
+    dir_pair = jd >> 1;                                                // pairs from dir_pair on hold only such nodes
+  }
+#ifdef LGAR_GEFFM_GENERAL_ONLY  // measurement: the general form throughout (what round 3 ran)
+  ser_pairs = 0; dir_pair = pairs + 1;
+#endif
+  int ser_all = safe_pairs;  // the wavefront's: min of ser_pairs (at most safe_pairs), max of dir_pair
+  if (any_lane(ser_pairs < ser_all) != 0ull) {
+    ser_all = 0;
+    for (int bit = 64; bit; bit >>= 1) {
+      const int cand = ser_all + bit;
+      if (cand <= safe_pairs && any_lane(ser_pairs < cand) == 0ull) ser_all = cand;
+    }
+  }
+  int dir_all = 0;
+  for (int bit = 64; bit; bit >>= 1) {
+    const int cand = dir_all + bit;
+    if (any_lane(dir_pair >= cand) != 0ull) dir_all = cand;
+  }
+  for (; it + 1 < ser_all; it += 2, ja = ja + four2, jb = jb + four2) LGAR_GEFFM_GROUP(false, 1)
+  const int it_a = it;
+  for (; it + 1 < safe_pairs && it < dir_all; it += 2, ja = ja + four2, jb = jb + four2) LGAR_GEFFM_GROUP(false, 0)
+  const int it_b = it;
+  for (; it + 1 < safe_pairs; it += 2, ja = ja + four2, jb = jb + four2) LGAR_GEFFM_GROUP(false, 2)
+  const int it_c = it;
+  for (; it + 1 < pairs; it += 2, ja = ja + four2, jb = jb + four2) LGAR_GEFFM_GROUP(true, 0)
+  LGAR_MEASURE_POINT(GEFFM_REGIONS, it_a >> 1, (it_b - it_a) >> 1, (it_c - it_b) >> 1, (it - it_c) >> 1)
 #undef LGAR_GEFFM_GROUP
   const int rem = M - 2 * it;  // interior nodes left over by the groups of four: 0..3 (3 for the reference's 120 intervals)
   if (rem > 0) {             // ... as one more group whose surplus nodes count as zero
     const f32x2 xa = __builtin_elementwise_fma(ja, dxh2, x0h2) + __builtin_elementwise_fma(ja, dxl2, x0l2);
     const f32x2 xb = __builtin_elementwise_fma(jb, dxh2, x0h2) + __builtin_elementwise_fma(jb, dxl2, x0l2);
     f32x2 sa, ta, sb, tb;
-    LGAR_GEFFM_PAIR(xa, sa, ta)
-    LGAR_GEFFM_PAIR(xb, sb, tb)
+    LGAR_GEFFM_PAIR(xa, sa, ta, 0)
+    LGAR_GEFFM_PAIR(xb, sb, tb, 0)
     f32x2 ka = sa * ta, kb = sb * tb;
     ka.x = (xa.x < xcutf) ? ksat1f : ka.x;
     ka.y = (xa.y < xcutf) ? ksat1f : ka.y;
@@ -774,12 +884,55 @@ __device__ __forceinline__ double geff_mixed(const LayerK<double> &l, double the
   const bool outside = is_nan(h_i) || is_nan(h_f);
   return outside ? res + (h_i + h_f) : res;
 }
+// calc_geff(theta1 -> theta2) in the mixed-precision mode: heads and end nodes from the two water contents (mixed_end)
+__device__ __forceinline__ double geff_mixed(const LayerK<double> &l, double theta1, double theta2, int nint) {
+  const double se_i = se_from_theta(l, theta1);
+  const double se_f = se_from_theta(l, theta2);
+  // K_r at Se == 1 (the 1e-12 nudge of calc_k_from_se): (1 - (1e-12)^m)^2
+  const double tsat = 1.0 - ex2p(l.m * LGAR_LOG2_1EM12);
+  const double ksat1 = tsat * tsat;
+  double h_i, h_f, k0, kn_own;
+  mixed_end(l, se_i, h_i, k0);
+  if (any_lane(se_f != 1.0) != 0ull) {
+    mixed_end(l, se_f, h_f, kn_own);
+  } else {  // every lane's wet end is saturated (theta_2 == theta_e: new fronts, infiltration): what mixed_end returns for Se == 1
+    h_f = (1.0 / l.alpha) * ex2e(LGAR_LOG2_1EM12 * l.inv_n);
+    kn_own = ksat1;
+  }
+  return geff_mixed_core(l, h_i, h_f, k0, kn_own, ksat1, nint);
+}
+// K(Se) / Ksat of both ends of a trapezoid (calc_k_from_se, utils.py:134-156, nudge included), the two evaluated in lockstep:
+// each is a chain of two logarithms and two exponentials in which every operation waits for the one before it.
+__device__ __forceinline__ void mixed_k_pair(const LayerK<double> &l, double se_a, double se_b, double &kr_a, double &kr_b) {
+  const double qa = lg2e(se_a) * l.inv_m, qb = lg2e(se_b) * l.inv_m;
+  const double oa = 1.0 - ex2e(qa), ob = 1.0 - ex2e(qb);  // 1 - Se^(1/m)
+  const double ba = (fabs(oa) <= 1e-8) ? oa + 1e-12 : oa, bb = (fabs(ob) <= 1e-8) ? ob + 1e-12 : ob;
+  const double ua = (oa == 0.0) ? LGAR_LOG2_1EM12 : lg2e(ba), ub = (ob == 0.0) ? LGAR_LOG2_1EM12 : lg2e(bb);
+  const double ta = 1.0 - ex2e(l.m * ua), tb = 1.0 - ex2e(l.m * ub);
+  kr_a = sqrt(se_a) * (ta * ta);
+  kr_b = sqrt(se_b) * (tb * tb);
+}
+// calc_geff(theta1 -> theta2) for two FRONTS of the table, mixed-precision mode (calc_dzdt, calc_dry_depth): the heads are the
+// fronts' own psi -- every front carries psi = h(Se(theta)) or the psi its theta was computed from (Column::move_wetting_front),
+// so h(Se(theta)) need not be formed again: it would differ from psi by the rounding of the round trip, ~1e-10 relative, three
+// orders below what the fp32 interior resolves -- and only K_r of the two end nodes is evaluated.  kr_f: K(theta2) / Ksat, which
+// calc_dzdt needs as the front's own conductivity (Layer.py:1212-1216) and would otherwise compute a second time.
+__device__ __forceinline__ double geff_mixed_heads(const LayerK<double> &l, double theta1, double theta2, double psi1, double psi2, int nint,
+                                                   double &kr_f) {
+  const double se_i = se_from_theta(l, theta1);
+  const double se_f = se_from_theta(l, theta2);
+  const double tsat = 1.0 - ex2p(l.m * LGAR_LOG2_1EM12);
+  const double ksat1 = tsat * tsat;
+  double k0, kn_own;
+  mixed_k_pair(l, se_i, se_f, k0, kn_own);
+  kr_f = kn_own;
+  return geff_mixed_core(l, psi1, psi2, k0, kn_own, ksat1, nint);
+}
 // calc_geff with use_closed_form_G (lgar/green_ampt.py:85-98): Brooks-Corey estimate from the van Genuchten parameters
 // (calc_bc_lambda / calc_bc_psib, physics/utils.py:54-64, 84-99).  Operator precedence as written in the reference:
 // geff = h_c * Se_i^e - Se_f^e / (1 - Se_f^e), with Se_f from theta_1 and Se_i from theta_2; inf/nan -> h_c.
 template <typename S, int POL = 0> __device__ __forceinline__ S geff_closed(const LayerK<S> &l, S theta1, S theta2) {
   using R = real_t<S>;
-  constexpr bool EX = POL == 1;
   const S p = R(1.0) + (R(2.0) / l.m);
   const S lambda = R(2.0) / (p - R(3.0));
   const S psib = (p + R(3.0)) * (R(147.8) + R(8.1) * p + R(0.092) * p * p) /
@@ -788,8 +941,8 @@ template <typename S, int POL = 0> __device__ __forceinline__ S geff_closed(cons
   const S se_i = se_from_theta(l, theta2);
   const S h_c = psib * (R(2.0) + R(3.0) * lambda) / (R(1.0) + R(3.0) * lambda);
   const S e = R(3.0) + R(1.0) / lambda;
-  const S pf = pwx<EX>(se_f, e);
-  S g = h_c * pwx<EX>(se_i, e) - pf / (R(1.0) - pf);
+  const S pf = pwq<S, POL>(se_f, e);
+  S g = h_c * pwq<S, POL>(se_i, e) - pf / (R(1.0) - pf);
   const R gv = val(g);
   if (gv != gv || gv - gv != R(0.0)) g = h_c;  // torch.isinf / torch.isnan
   return g;
@@ -872,7 +1025,8 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
   using R = real_t<S>;
   // arithmetic policy (see dv / pwx): verification mode in double precision uses the library pow (the reference's
   // torch.pow); the plain-float fast mode divides by reciprocal; everything else is lean pow + IEEE division
-  static constexpr int POL = ((MODE == 0) && (sizeof(R) == 8)) ? 1 : (((MODE != 0) && (sizeof(S) == 4)) ? 2 : 0);
+  // (3: MODE 3, the mixed-precision kernels -- lean pow with pairwise-combined polynomials, see fast_pow)
+  static constexpr int POL = ((MODE == 0) && (sizeof(R) == 8)) ? 1 : (((MODE != 0) && (sizeof(S) == 4)) ? 2 : ((MODE == 3 && sizeof(S) == 8) ? 3 : 0));
   static constexpr int STRIDE = (MODE == 4) ? LGAR_COOP_GROUPS : WAVE;  // front-table slots per row (see FrontsView)
   const ColParams<S, NL> &P;
   const LGAR_KARG Glob<R> *G;  // run-time constants, in the kernarg segment (re-pointed by the kernel's time loop)
@@ -925,6 +1079,14 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
       if (!G->closed_form) return geff_mixed(lk, theta1, theta2, G->nint);
     }
     return G->closed_form ? geff_closed<S, POL>(lk, theta1, theta2) : geff(lk, theta1, theta2, G->nint);
+  }
+  // calc_geff between two FRONTS of the table in the mixed-precision mode (calc_dzdt): the fronts' own psi are the trapezoid's
+  // heads, and K(theta2) / Ksat of its wet end node is handed back -- the front's own conductivity (geff_mixed_heads).
+  __device__ __forceinline__ double capillary_drive_fronts(const LayerK<double> &lk, double theta1, double theta2, double psi1,
+                                                           double psi2, double &kr_end) {
+    LGAR_MEASURE_POINT(NOGEFF_FRONTS, lk, theta1, theta2, kr_end)
+    LGAR_COUNT_GEFF_CALL(1)
+    return geff_mixed_heads(lk, theta1, theta2, psi1, psi2, G->nint, kr_end);
   }
   __device__ __forceinline__ S cum_prev(int k) const {  // cum[k-1], 0 for k == 0
     S r = S(R(0.0));
@@ -988,9 +1150,9 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
   // theta(psi) and d theta / d psi of one layer in plain reals (no extra pow for the slope:
   // theta' = -(theta - theta_r) m n (a psi)^n / (psi (1 + (a psi)^n)))
   __device__ __forceinline__ static void theta_slope(R alpha, R n, R m, R te, R tr, R psi, R &th, R &dth) {
-    R ap = pw(alpha * psi, n);
+    R ap = pwp<POL>(alpha * psi, n);
     R one_ap = R(1.0) + ap;
-    R op = pw(one_ap, m);
+    R op = pwp<POL>(one_ap, m);
     R span = dv<POL>(R(1.0), op) * (te - tr);
     th = span + tr;
     dth = (psi > R(0.0)) ? dv<POL>(-(span * m * n * ap), psi * one_ap) : R(0.0);
@@ -1515,9 +1677,22 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
         const LayerK<S> lk = pick(P, k);
         S theta_1 = F.TH(i + 1), theta_2 = F.TH(i);
         S delta_theta = F.TH(i) - F.TH(i + 1);
-        S g = capillary_drive(lk, theta_1, theta_2, 1);
+        S g, ki;
+        bool fronts_done = false;
+        if constexpr (MODE == 3 && sizeof(S) == 8 && sizeof(R) == 8) {
+          if (!G->closed_form) {  // mixed precision: heads from the fronts' psi, K(theta_i) from the trapezoid's wet end node
+            double kr_end;
+            g = capillary_drive_fronts(lk, theta_1, theta_2, F.PS(i + 1), F.PS(i), kr_end);
+            ki = lk.ksat * kr_end;
+            if (i == 0 && new_front_frozen) ki = ki * G->frozen;
+            fronts_done = true;
+          }
+        }
+        if (!fronts_done) {
+          g = capillary_drive(lk, theta_1, theta_2, 1);
+          ki = front_k(i, lk);
+        }
         if (is_nan(val(g))) status |= LGAR_ST_NAN;
-        const S ki = front_k(i, lk);
         S dzdt;
         if (k == 0) {
           dzdt = dv<POL>(S(R(1.0)), delta_theta) * (dv<POL>(lk.ksat * (g + h_p), F.Z(i)) + ki);

@@ -159,6 +159,11 @@ static void launch_fast_kernel(KArgs<R> &a, unsigned nblocks, unsigned *ticket, 
       launch_forward_kernel<R, NL, CAP, 3>(a, nblocks, ticket, st);
       return;
     }
+  }
+#if defined(LGAR_MEASURE) && defined(LGAR_ONLY_MIXED)  // measurement builds that compile the mixed-precision kernels only
+  (void)nblocks; (void)ticket; (void)st;
+#else
+  if constexpr (sizeof(R) == 8) {
     if (a.coop > 1) {  // cooperating lanes: the 32-front kernel, whose LDS is per group of lanes (forward_typed)
       if constexpr (CAP == LGAR_FMAX) launch_forward_kernel<R, NL, CAP, 4>(a, nblocks, ticket, st);
       return;
@@ -166,6 +171,7 @@ static void launch_fast_kernel(KArgs<R> &a, unsigned nblocks, unsigned *ticket, 
   }
   (void)mixed;
   launch_forward_kernel<R, NL, CAP, 1>(a, nblocks, ticket, st);
+#endif
 }
 
 // The front-capacity chain of one lgar_forward call (see lgar_forward_body.hpp).
@@ -177,11 +183,13 @@ static int forward_typed(const LgarDims *dims, const LgarParams *params, LgarSta
   const int slots = a.F;
   unsigned *tickets = state->tickets;
   if (tickets != nullptr && hipMemsetAsync(tickets, 0, LGAR_NTICKETS * sizeof(unsigned), st) != hipSuccess) return LGAR_E_LAUNCH;
+#if !(defined(LGAR_MEASURE) && (defined(LGAR_ONLY_MIXED) || defined(LGAR_ONLY_F32)))
   if (dims->search_mode == 0) {
     // the reference's literal searches: verification mode, one kernel at the full capacity
     launch_forward_kernel<R, NL, LGAR_FMAX, 0>(a, grid, tickets, st);
     return launch_status();
   }
+#endif
   // smallest capacity that leaves room for a forcing step (one front per layer + one new front per sub-step + slack);
   // small jobs (under one wave per SIMD) gain nothing from occupancy and start at the full capacity
   const int need = NL + dims->num_subcycles + 2;
@@ -223,10 +231,22 @@ int launch_init_nl(const LgarDims *dims, const LgarParams *params, LgarState *st
 template <int NL>
 int launch_forward_nl(const LgarDims *dims, const LgarParams *params, LgarState *state, const LgarForcing *forcing,
                       const LgarStepOut *out, int32_t *status, int dtype, hipStream_t st) {
+#if !(defined(LGAR_MEASURE) && defined(LGAR_ONLY_F32))  // (measurement builds of the fp32 kernels alone)
   if (dtype == LGAR_F64) return forward_typed<double, NL>(dims, params, state, forcing, out, status, st);
+#endif
   if (dtype == LGAR_F32) return forward_typed<float, NL>(dims, params, state, forcing, out, status, st);
   return LGAR_E_ARG;
 }
+
+#ifdef LGAR_MEASURE
+// measurement builds: read (and zero) the debug counters of this translation unit (lgar_measure.hpp)
+extern "C" int lgar_debug_counters(unsigned long long *out, int reset) {
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(lgar_dbg_counters), sizeof(z)) != hipSuccess) return -1;
+  if (reset && hipMemcpyToSymbol(HIP_SYMBOL(lgar_dbg_counters), z, sizeof(z)) != hipSuccess) return -1;
+  return 0;
+}
+#endif
 
 template int launch_init_nl<LGAR_NL>(const LgarDims *, const LgarParams *, LgarState *, int32_t *, int, hipStream_t);
 template int launch_forward_nl<LGAR_NL>(const LgarDims *, const LgarParams *, LgarState *, const LgarForcing *,

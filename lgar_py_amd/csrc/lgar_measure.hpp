@@ -39,6 +39,11 @@ __device__ __forceinline__ double opaque(double x) { asm volatile("" : "+v"(x));
 #else
 #define LGAR_POINT_NOGEFF(lk, theta1, theta2)
 #endif
+#ifdef LGAR_ABL_NOGEFF
+#define LGAR_POINT_NOGEFF_FRONTS(lk, theta1, theta2, kr) { kr = theta1; return theta1 * theta2 + lk.alpha; }
+#else
+#define LGAR_POINT_NOGEFF_FRONTS(lk, theta1, theta2, kr)
+#endif
 #ifdef LGAR_COUNT_SITE  // count one call site only (1 dzdt, 2 dry depth, 3 insert)
 #define LGAR_COUNT_IF_SITE(site) if (site == LGAR_COUNT_SITE)
 #else
@@ -114,4 +119,21 @@ __device__ __forceinline__ double opaque(double x) { asm volatile("" : "+v"(x));
   if (val(volume) == R(-1.0)) status |= LGAR_ST_STRUCT; /* never true */
 #else
 #define LGAR_POINT_DUP_MB(volume)
+#endif
+
+// ---- geff_mixed: how many four-node groups each of its loops ran (series-only / general / difference-only / checked), per
+// wave-level evaluation; read back with lgar_debug_counters (lgar_kernels_nl.hip, measurement builds only)
+static __device__ unsigned long long lgar_dbg_counters[8];
+#ifndef LGAR_COUNT_GEFFM_REGIONS
+#define LGAR_POINT_GEFFM_REGIONS(a, b, c, d)
+#else
+#define LGAR_POINT_GEFFM_REGIONS(a, b, c, d)                                                        \
+  if (first_active_lane()) {                                                                       \
+    atomicAdd(&lgar_dbg_counters[0], (unsigned long long)(a));                                     \
+    atomicAdd(&lgar_dbg_counters[1], (unsigned long long)(b));                                     \
+    atomicAdd(&lgar_dbg_counters[2], (unsigned long long)(c));                                     \
+    atomicAdd(&lgar_dbg_counters[3], (unsigned long long)(d));                                     \
+    atomicAdd(&lgar_dbg_counters[4], 1ull);                                                        \
+    atomicAdd(&lgar_dbg_counters[5], (unsigned long long)__builtin_popcountll(any_lane(true)));    \
+  }
 #endif

@@ -127,7 +127,8 @@ int tangent_typed(const LgarDims *d, const LgarParams *p, const LgarParams *dir,
 
 extern "C" {
 
-// element-wise access to the lean fp64 math (lgar_math.hpp): op 0 exp2, 1 log2, 2 pow(x, y), 3 exp2_core, 4 log2_core
+// element-wise access to the lean fp64 math (lgar_math.hpp): op 0 exp2, 1 log2, 2 pow(x, y), 3 exp2_core, 4 log2_core;
+// 10..14: the same with the polynomials' high-order terms combined pairwise (ESTRIN: the mixed-precision kernels)
 void devsim_math(int op, int n, const double *x, const double *y, double *out) {
   for (int i = 0; i < n; i++) {
     switch (op) {
@@ -136,6 +137,11 @@ void devsim_math(int op, int n, const double *x, const double *y, double *out) {
       case 2: out[i] = fast_pow(x[i], y[i]); break;
       case 3: out[i] = fast_exp2_core<false>(x[i]); break;
       case 4: out[i] = fast_log2_core(x[i]); break;
+      case 10: out[i] = fast_exp2<true>(x[i]); break;
+      case 11: out[i] = fast_log2<true>(x[i]); break;
+      case 12: out[i] = fast_pow<true>(x[i], y[i]); break;
+      case 13: out[i] = fast_exp2_core<false, true>(x[i]); break;
+      case 14: out[i] = fast_log2_core<true>(x[i]); break;
     }
   }
 }

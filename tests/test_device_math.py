@@ -20,46 +20,49 @@ def _call(op, x, y=None):
     return out
 
 
-def test_exp2_relative_error():
+@pytest.mark.parametrize("v", [0, 10], ids=["horner", "pairwise"])
+def test_exp2_relative_error(v):
     mp.mp.dps = 40
     rng = np.random.default_rng(0)
     x = np.concatenate([rng.uniform(-60, 60, 4000), rng.uniform(-1, 1, 2000), [0.0, 0.5, -0.5, 1.0, -1022.0, 1023.0]])
-    got = _call(0, x)
-    ref = [mp.mpf(2) ** mp.mpf(float(v)) for v in x]
+    got = _call(v + 0, x)
+    ref = [mp.mpf(2) ** mp.mpf(float(u)) for u in x]
     rel = max(abs((mp.mpf(float(g)) - r) / r) for g, r in zip(got, ref))
     assert rel <= 2.5e-16, rel  # one rounding of the result + 3.2e-18 polynomial error
-    assert np.array_equal(_call(3, x), got)  # the unclamped core used inside the trapezoid: same values on finite input
-    sp = _call(0, [np.nan, -np.inf, np.inf, -2000.0, 2000.0])
+    assert np.array_equal(_call(v + 3, x), got)  # the unclamped core used inside the trapezoid: same values on finite input
+    sp = _call(v + 0, [np.nan, -np.inf, np.inf, -2000.0, 2000.0])
     assert np.isnan(sp[0]) and sp[1] == 0.0 and np.isinf(sp[2]) and sp[3] == 0.0 and np.isinf(sp[4])
 
 
-def test_log2_absolute_error():
+@pytest.mark.parametrize("v", [0, 10], ids=["horner", "pairwise"])
+def test_log2_absolute_error(v):
     mp.mp.dps = 40
     rng = np.random.default_rng(1)
     x = np.concatenate([np.exp(rng.uniform(-80, 80, 4000)), rng.uniform(0.5, 2.0, 3000), [1.0, 0.5, 2.0, 5e-324, 1e308]])
-    got = _call(1, x)
-    err = max(abs(mp.mpf(float(g)) - mp.log(mp.mpf(float(v)), 2)) / max(1, abs(mp.log(mp.mpf(float(v)), 2))) for g, v in zip(got, x))
+    got = _call(v + 1, x)
+    err = max(abs(mp.mpf(float(g)) - mp.log(mp.mpf(float(u)), 2)) / max(1, abs(mp.log(mp.mpf(float(u)), 2))) for g, u in zip(got, x))
     assert err <= 2.5e-16, err  # absolute for |log2 x| <= 1, relative beyond
-    assert np.array_equal(_call(4, x), got)
+    assert np.array_equal(_call(v + 4, x), got)
     # near x = 1 the result is accurate relative to ITSELF (1 - Se^(1/m) in calc_k_from_se needs (1 - eps)^m - 1)
     eps = np.concatenate([10.0 ** rng.uniform(-17, -2, 2000), -(10.0 ** rng.uniform(-17, -2, 2000))])
     xn = 1.0 + eps
-    gn = _call(1, xn)
+    gn = _call(v + 1, xn)
     nz = xn != 1.0
-    reln = max(abs((mp.mpf(float(g)) - mp.log(mp.mpf(float(v)), 2)) / mp.log(mp.mpf(float(v)), 2)) for g, v in zip(gn[nz], xn[nz]))
+    reln = max(abs((mp.mpf(float(g)) - mp.log(mp.mpf(float(u)), 2)) / mp.log(mp.mpf(float(u)), 2)) for g, u in zip(gn[nz], xn[nz]))
     assert reln <= 4e-16, reln
     assert (gn[~nz] == 0.0).all()
-    sp = _call(1, [0.0, -1.0, np.nan, np.inf])
+    sp = _call(v + 1, [0.0, -1.0, np.nan, np.inf])
     assert sp[0] == -np.inf and np.isnan(sp[1]) and np.isnan(sp[2]) and sp[3] == np.inf
 
 
-def test_pow_in_the_van_genuchten_range():
+@pytest.mark.parametrize("v", [0, 10], ids=["horner", "pairwise"])
+def test_pow_in_the_van_genuchten_range(v):
     """pow as the leaf functions use it (physics/utils.py): bases 1e-12 .. 1e6, exponents -12 .. 12."""
     mp.mp.dps = 40
     rng = np.random.default_rng(2)
     x = np.exp(rng.uniform(np.log(1e-12), np.log(1e6), 6000))
     y = rng.uniform(-12, 12, 6000)
-    got = _call(2, x, y)
+    got = _call(v + 2, x, y)
     worst = 0
     for g, a, b in zip(got, x, y):
         r = mp.mpf(float(a)) ** mp.mpf(float(b))
@@ -67,7 +70,7 @@ def test_pow_in_the_van_genuchten_range():
             cond = max(1.0, abs(float(b) * float(mp.log(mp.mpf(float(a)), 2))))
             worst = max(worst, float(abs((mp.mpf(float(g)) - r) / r)) / cond)
     assert worst <= 8e-16, worst  # relative error per unit of max(1, |y log2 x|); observed 6.7e-16
-    assert np.isnan(_call(2, [-2.0], [0.5])[0])  # negative base: NaN, what the status word reports as NEGBASE
+    assert np.isnan(_call(v + 2, [-2.0], [0.5])[0])  # negative base: NaN, what the status word reports as NEGBASE
 
 
 def test_polynomial_coefficients_are_the_chebyshev_fits():

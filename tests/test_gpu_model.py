@@ -238,12 +238,11 @@ def test_in_kernel_basin_aggregation():
             assert torch.allclose(outw["basin:runoff"], refw, rtol=tol * 10, atol=tol * 10 * float(refw.abs().max()))
 
 
-def test_basin_sums_two_ways(monkeypatch):
+def test_basin_sums_two_ways():
     """LgarStepOut.basin: where the series is stored, the basin sum is a second, deterministic pass over it
     (lgar_basin_reduce_kernel: same bits on every run); without a series the forward kernels reduce it themselves (atomics).
     Both equal the weighted column sum of the series; LgarEngine.forward puts a scratch series behind a basin-only request."""
     import lgar_py_amd as lg
-    from lgar_py_amd import engine as E
     from lgar_py_amd import workloads as W
     for N, dtype, tol in ((5000, torch.float64, 1e-13), (9001, torch.float32, 1e-6), (777, torch.float64, 1e-13)):  # 16-byte rows or not
         P = W.perturbed_columns(N, seed=5)
@@ -263,15 +262,24 @@ def test_basin_sums_two_ways(monkeypatch):
         assert torch.equal(a["basin:runoff"], b["basin:runoff"]) and torch.equal(a["basin:infiltration"], b["basin:infiltration"])
         assert eng._basin_scratch[0] == 144 and list(eng._basin_scratch[1]) == ["infiltration"]
         # the same request with no buffer behind it: the forward kernels' own reduction
-        monkeypatch.setattr(E, "BASIN_SCRATCH_BYTES", 0)
         eng2 = lg.LgarEngine(P["alpha"], P["n"], P["ksat"], P["theta_e"], P["theta_r"], P["thickness"], dt_h=300.0 / 3600.0,
-                             ponded_depth_max=0.0, dtype=dtype)
+                             ponded_depth_max=0.0, dtype=dtype, basin_scratch_bytes=0)
         c = eng2.forward(pr, pe, series=(), basin=("runoff", "infiltration"), weights=w, check=False)
         assert eng2._basin_scratch[1] == {}
         for nm in ("runoff", "infiltration"):
             s = float(a["basin:" + nm].abs().max())
             assert float((c["basin:" + nm] - a["basin:" + nm]).abs().max()) <= 10 * tol * s, (N, nm)
-        monkeypatch.undo()
+        # the cap is over ALL names of an engine: room for one series only -> the second name falls back to the kernels' own sums
+        one = 144 * N * (8 if dtype == torch.float64 else 4)
+        eng3 = lg.LgarEngine(P["alpha"], P["n"], P["ksat"], P["theta_e"], P["theta_r"], P["thickness"], dt_h=300.0 / 3600.0,
+                             ponded_depth_max=0.0, dtype=dtype, basin_scratch_bytes=one)
+        d = eng3.forward(pr, pe, series=(), basin=("runoff", "infiltration"), weights=w, check=False)
+        assert list(eng3._basin_scratch[1]) == ["runoff"]
+        for nm in ("runoff", "infiltration"):
+            s = float(a["basin:" + nm].abs().max())
+            assert float((d["basin:" + nm] - a["basin:" + nm]).abs().max()) <= 10 * tol * s, (N, nm)
+        eng3.release_scratch()
+        assert eng3._basin_scratch[1] == {}
 
 
 def test_forcing_broadcast_on_gpu():

@@ -38,6 +38,17 @@ VARIANTS = {
     "cf_nounroll": ["-fno-unroll-loops"], "cf_metricbias": ["-mllvm", "-amdgpu-schedule-metric-bias=30"], "cf_trackers": ["-mllvm", "-amdgpu-use-amdgpu-trackers"],
     "cf_iterative": ["-mllvm", "-amdgpu-sched-strategy=iterative-minreg"], "cf_nohighrp": ["-mllvm", "-amdgpu-disable-unclustered-high-rp-reschedule"],
     "tan_base": [], "tan_maxilp": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"], "tan_f32w1": ["-DLGAR_TAN_F32_WAVES=1"],
+    # mixed-precision kernels only (quick to build): experiments on geff_mixed, run with `ablate.py run mix`
+    "mx_base": ["-DLGAR_ONLY_MIXED"], "mx_general": ["-DLGAR_ONLY_MIXED", "-DLGAR_GEFFM_GENERAL_ONLY"],
+    "mx_regions": ["-DLGAR_ONLY_MIXED", "-DLGAR_COUNT_GEFFM_REGIONS"],
+    "mx_ieeediv": ["-DLGAR_ONLY_MIXED", "-DLGAR_IEEE_DIV"],
+    "mx_noheads": ["-DLGAR_ONLY_MIXED", "-DLGAR_NO_HEADS"], "mx_nodedupe": ["-DLGAR_ONLY_MIXED", "-DLGAR_NO_DEDUPE"],
+    "mx_neither": ["-DLGAR_ONLY_MIXED", "-DLGAR_NO_HEADS", "-DLGAR_NO_DEDUPE"],
+    "mx_estrin": ["-DLGAR_ONLY_MIXED", "-DLGAR_ESTRIN"],
+    "f32_only": ["-DLGAR_ONLY_F32"], "f32_noheads": ["-DLGAR_ONLY_F32", "-DLGAR_NO_HEADS_ARG"],
+    "mx_occ1": ["-DLGAR_ONLY_MIXED", "-DLGAR_OCC_F64_SMALL=1"],
+    "mx_occ1_ilp": ["-DLGAR_ONLY_MIXED", "-DLGAR_OCC_F64_SMALL=1", "-mllvm", "-amdgpu-sched-strategy=max-ilp"],
+    "mx_ilp": ["-DLGAR_ONLY_MIXED", "-mllvm", "-amdgpu-sched-strategy=max-ilp"],
     "occ3": ["-DLGAR_OCC_F32_SMALL=3"],
     "occ2": ["-DLGAR_OCC_F32_SMALL=2"],
     "occ1_f64": ["-DLGAR_OCC_F64_SMALL=1"],
@@ -69,7 +80,13 @@ for rep in range(%(reps)d):
     b.record(); torch.cuda.synchronize()
     ms.append(a.elapsed_time(b))
 ms = sorted(ms[1:])
-print(json.dumps(dict(variant=%(name)r, dtype=%(dt)r, columns=N, ms_median=ms[len(ms) // 2], ms_min=ms[0],
+dbg = None
+if hasattr(eng.lib, "lgar_debug_counters"):
+    import ctypes
+    buf = (ctypes.c_ulonglong * 8)()
+    if eng.lib.lgar_debug_counters(buf, 1) == 0:
+        dbg = list(buf)
+print(json.dumps(dict(variant=%(name)r, dtype=%(dt)r, columns=N, ms_median=ms[len(ms) // 2], ms_min=ms[0], dbg=dbg,
                       col_steps_per_s=N * T / (ms[len(ms) // 2] * 1e-3), faulted=int((eng.status != 0).sum()),
                       geff_calls=int(eng.geff_wave_calls()), runoff_sum=float(out["runoff"].double().sum()))))
 """
