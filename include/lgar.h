@@ -222,6 +222,8 @@ int32_t lgar_forward_tangent(const LgarDims *dims, const LgarParams *params, con
  * op 7 log2(x), 8 exp2(x) as the Geff trapezoid evaluates them, 9 pow(x, y) as the fast modes evaluate torch.pow
  *      (accuracy of the device arithmetic on the real hardware; soil parameters unused but required)
  * op 10 geff(theta1 = x, theta2 = y) by the mixed-precision trapezoid of LgarDims.geff_mode = 1 (LGAR_F64; LGAR_F32: op 4)
+ * op 11 x / y as the fast modes divide (LGAR_F64: reciprocal + Newton + correction, within an ulp of the IEEE quotient)
+ * op 12 pow(x, y), 13 log2(x), 14 exp2(x) as the mixed-precision kernels evaluate them (polynomial terms combined pairwise)
  * alpha, n, ksat, theta_e, theta_r: [n] per-item soil parameters. */
 int32_t lgar_leaf_batch(int32_t op, int32_t n_items, const void *x, const void *y, double z, const void *alpha,
                         const void *n, const void *ksat, const void *theta_e, const void *theta_r, int32_t nint,

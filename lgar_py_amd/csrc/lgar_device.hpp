@@ -835,9 +835,7 @@ __device__ __forceinline__ double geff_mixed_core(const LayerK<double> &l, doubl
     const int jd = !(jd_f < double(M + 2)) ? M + 2 : ((jd_f > 0.0) ? int(jd_f) : 0);
     dir_pair = jd >> 1;                                                // pairs from dir_pair on hold only such nodes
   }
-#ifdef LGAR_GEFFM_GENERAL_ONLY  // measurement: the general form throughout (what round 3 ran)
-  ser_pairs = 0; dir_pair = pairs + 1;
-#endif
+  LGAR_MEASURE_POINT(GEFFM_GENERAL_ONLY, ser_pairs, dir_pair, pairs)
   int ser_all = safe_pairs;  // the wavefront's: min of ser_pairs (at most safe_pairs), max of dir_pair
   if (any_lane(ser_pairs < ser_all) != 0ull) {
     ser_all = 0;

@@ -25,6 +25,14 @@ template <typename R> __device__ __forceinline__ Dual<R> choose(bool c, const Du
   return Dual<R>(c ? a.v : b.v, c ? a.d : b.d);
 }
 
+// a / b where the quotient feeds a DERIVATIVE only: in double precision by reciprocal (v_rcp_f64 + two Newton steps, ~1 ulp: a
+// third of the instructions of the IEEE divide, in kernels whose every instruction is on a lone wave's critical path); single
+// precision keeps its divide (the fp32 tangent kernels sit exactly at their register budget)
+template <typename R> __device__ __forceinline__ R dquot(R a, R b) {
+  if constexpr (sizeof(R) == 8) return a * fast_recip(b);
+  else return a / b;
+}
+
 #define LGAR_DUAL_BIN(OP, VEXPR, DEXPR_DD, DEXPR_DR, DEXPR_RD)                                                          \
   template <typename R> __device__ __forceinline__ Dual<R> operator OP(const Dual<R> &a, const Dual<R> &b) {            \
     const R av = a.v, bv = b.v, ad = a.d, bd = b.d; (void)av; (void)bv; (void)ad; (void)bd;                             \
@@ -42,7 +50,8 @@ template <typename R> __device__ __forceinline__ Dual<R> choose(bool c, const Du
 LGAR_DUAL_BIN(+, av + bv, ad + bd, ad, bd)
 LGAR_DUAL_BIN(-, av - bv, ad - bd, ad, -bd)
 LGAR_DUAL_BIN(*, av * bv, ad * bv + av * bd, ad * bv, av * bd)
-LGAR_DUAL_BIN(/, av / bv, (ad - (av / bv) * bd) / bv, ad / bv, -((av / bv) * bd) / bv)
+// (the value is the IEEE quotient the plain kernels form where they write a / b; the tangent divides by reciprocal)
+LGAR_DUAL_BIN(/, av / bv, dquot(ad - (av / bv) * bd, bv), dquot(ad, bv), dquot(-((av / bv) * bd), bv))
 #undef LGAR_DUAL_BIN
 
 template <typename R> __device__ __forceinline__ Dual<R> operator-(const Dual<R> &a) { return Dual<R>(-a.v, -a.d); }
@@ -53,13 +62,32 @@ template <typename R> __device__ __forceinline__ Dual<R> pw(const Dual<R> &x, co
   const R l2 = lg2(x.v);
   const R v = ex2(y.v * l2);
   R d = R(0);
-  if (x.v > R(0)) d = v * (y.d * (R(0.6931471805599453) * l2) + y.v * x.d / x.v);
+  if (x.v > R(0)) d = v * (y.d * (R(0.6931471805599453) * l2) + dquot(y.v * x.d, x.v));
   return Dual<R>(v, d);
 }
-// division policy (dv in lgar_device.hpp): dual numbers always divide exactly
-template <int POL, typename R> __device__ __forceinline__ Dual<R> dv(const Dual<R> &a, const Dual<R> &b) { return a / b; }
-template <int POL, typename R> __device__ __forceinline__ Dual<R> dv(const Dual<R> &a, R b) { return a / b; }
-template <int POL, typename R> __device__ __forceinline__ Dual<R> dv(R a, const Dual<R> &b) { return a / b; }
+// division policy (dv in lgar_device.hpp).  The VALUE of a quotient goes through exactly what the plain kernels' dv does with the
+// same policy (a tangent launch and the forward launch it differentiates must walk the same trajectory): in the double-precision
+// fast modes that is lean_div; the tangent reuses its refined reciprocal instead of dividing a second and a third time.
+template <int POL, typename R> __device__ __forceinline__ Dual<R> dv(const Dual<R> &a, const Dual<R> &b) {
+  if constexpr ((POL == 0 || POL == 3) && sizeof(R) == 8) {
+    const R q = lean_div(a.v, b.v);
+    return Dual<R>(q, (a.d - q * b.d) * fast_recip(b.v));
+  } else {
+    return a / b;
+  }
+}
+template <int POL, typename R> __device__ __forceinline__ Dual<R> dv(const Dual<R> &a, R b) {
+  if constexpr ((POL == 0 || POL == 3) && sizeof(R) == 8) return Dual<R>(lean_div(a.v, b), a.d * fast_recip(b));
+  else return a / b;
+}
+template <int POL, typename R> __device__ __forceinline__ Dual<R> dv(R a, const Dual<R> &b) {
+  if constexpr ((POL == 0 || POL == 3) && sizeof(R) == 8) {
+    const R q = lean_div(a, b.v);
+    return Dual<R>(q, -(q * b.d) * fast_recip(b.v));
+  } else {
+    return a / b;
+  }
+}
 // verification mode (see pwx in lgar_device.hpp): correctly rounded pow / log for the value and the derivative
 template <bool EX, typename R> __device__ __forceinline__ Dual<R> pwx(const Dual<R> &x, const Dual<R> &y) {
   if constexpr (EX && sizeof(R) == 8) {
@@ -72,7 +100,7 @@ template <bool EX, typename R> __device__ __forceinline__ Dual<R> pwx(const Dual
 }
 template <typename R> __device__ __forceinline__ Dual<R> sq(const Dual<R> &x) {
   const R v = sq(x.v);
-  return Dual<R>(v, (v > R(0)) ? x.d / (R(2) * v) : R(0));
+  return Dual<R>(v, (v > R(0)) ? dquot(x.d, R(2) * v) : R(0));
 }
 template <typename R> __device__ __forceinline__ Dual<R> ab(const Dual<R> &x) {
   return Dual<R>(ab(x.v), (x.v > R(0)) ? x.d : ((x.v < R(0)) ? -x.d : R(0)));
@@ -85,7 +113,7 @@ template <typename R> __device__ __forceinline__ Dual<R> mn(const Dual<R> &a, co
 
 // log2 / exp2 (the fused Geff node, lgar_device.hpp): d log2 x = dx / (x ln 2), d 2^y = 2^y ln 2 dy
 template <typename R> __device__ __forceinline__ Dual<R> lg2(const Dual<R> &x) {
-  return Dual<R>(lg2(x.v), (x.v > R(0)) ? x.d / (x.v * R(0.6931471805599453)) : R(0));
+  return Dual<R>(lg2(x.v), (x.v > R(0)) ? dquot(x.d, x.v * R(0.6931471805599453)) : R(0));
 }
 template <typename R> __device__ __forceinline__ Dual<R> ex2(const Dual<R> &y) {
   const R v = ex2(y.v);

@@ -46,6 +46,16 @@ template <typename R> __global__ void lgar_leaf_kernel(LeafArgs<R> a) {
       if constexpr (sizeof(R) == 8) r = geff_mixed(l, x, y, a.nint);
       else r = geff(l, x, y, a.nint);
       break;
+    case 11: r = dv<0>(x, y); break;        // the fast modes' quotient (double precision: lean_div)
+    case 12: r = pwp<3>(x, y); break;       // the mixed-precision kernels' pow (pairwise-combined polynomials)
+    case 13:
+      if constexpr (sizeof(R) == 8) r = lg2e(x);
+      else r = lg2p(x);
+      break;
+    case 14:
+      if constexpr (sizeof(R) == 8) r = ex2e(x);
+      else r = ex2p(x);
+      break;
   }
   a.out[i] = r;
 }
@@ -229,7 +239,7 @@ int32_t lgar_forward_tangent(const LgarDims *dims, const LgarParams *params, con
 int32_t lgar_leaf_batch(int32_t op, int32_t n_items, const void *x, const void *y, double z, const void *alpha,
                         const void *n, const void *ksat, const void *theta_e, const void *theta_r, int32_t nint,
                         double wilting_point_psi, void *out, int32_t dtype, void *stream) {
-  if (op < 0 || op > 10 || n_items <= 0 || !x || !alpha || !n || !ksat || !theta_e || !theta_r || !out) return LGAR_E_ARG;
+  if (op < 0 || op > 14 || n_items <= 0 || !x || !alpha || !n || !ksat || !theta_e || !theta_r || !out) return LGAR_E_ARG;
   if ((op == 4 || op == 5 || op == 6 || op == 10) && !y) return LGAR_E_ARG;
   const unsigned grid = (unsigned)((n_items + 255) / 256);
   hipStream_t st = (hipStream_t)stream;

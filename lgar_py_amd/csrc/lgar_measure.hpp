@@ -121,6 +121,12 @@ __device__ __forceinline__ double opaque(double x) { asm volatile("" : "+v"(x));
 #define LGAR_POINT_DUP_MB(volume)
 #endif
 
+// ---- geff_mixed: the general node form throughout (what round 3 ran)
+#ifdef LGAR_GEFFM_GENERAL_ONLY
+#define LGAR_POINT_GEFFM_GENERAL_ONLY(ser_pairs, dir_pair, pairs) ser_pairs = 0; dir_pair = pairs + 1;
+#else
+#define LGAR_POINT_GEFFM_GENERAL_ONLY(ser_pairs, dir_pair, pairs)
+#endif
 // ---- geff_mixed: how many four-node groups each of its loops ran (series-only / general / difference-only / checked), per
 // wave-level evaluation; read back with lgar_debug_counters (lgar_kernels_nl.hip, measurement builds only)
 static __device__ unsigned long long lgar_dbg_counters[8];

@@ -399,7 +399,7 @@ def leaf_batch(op, x, y=None, z=0.0, *, alpha, n, ksat, theta_e, theta_r, nint=1
     _require_gpu(dev)
     lib = _capi.load()
     ops = {"theta_from_h": 0, "se_from_h": 1, "k_from_se": 2, "h_from_se": 3, "geff": 4, "aet": 5, "geff_literal": 6,
-           "log2": 7, "exp2": 8, "pow": 9, "geff_mixed": 10}
+           "log2": 7, "exp2": 8, "pow": 9, "geff_mixed": 10, "div": 11, "pow_pairwise": 12, "log2_pairwise": 13, "exp2_pairwise": 14}
     prep = lambda t: None if t is None else torch.as_tensor(t, dtype=torch.float64).to(dev, dtype).contiguous()
     x, y, alpha, n, ksat, theta_e, theta_r = map(prep, (x, y, alpha, n, ksat, theta_e, theta_r))
     out = torch.empty_like(x)

@@ -230,3 +230,36 @@ def test_device_log2_exp2_pow_accuracy_on_hardware():
     got = lg.leaf_batch("pow", xb, yb, **kw).cpu().numpy().astype(L)
     ref = np.power(xb.astype(L), yb.astype(L))
     assert float(np.max(np.abs(got - ref) / ref)) <= 5e-14
+
+
+def test_lean_division_and_pairwise_polynomials_on_hardware():
+    """The fast modes' double-precision quotient (v_rcp_f64 + one Newton step + one correction, lgar_device.hpp lean_div) against
+    the exact quotient: <= 1 ulp (2.3e-16 relative; measured 1.2e-16), over the magnitudes the column physics divides; and the
+    mixed-precision kernels' log2 / exp2 / pow (high-order terms combined pairwise) to the bounds of the Horner forms."""
+    import lgar_py_amd as lg
+    rng = np.random.default_rng(1)
+    n = 1 << 18
+    one = np.ones(n)
+    kw = dict(alpha=one, n=one * 2, ksat=one, theta_e=one, theta_r=one * 0)
+    L = np.longdouble
+    a = np.exp(rng.uniform(np.log(1e-12), np.log(1e12), n)) * rng.choice([-1.0, 1.0], n)
+    b = np.exp(rng.uniform(np.log(1e-12), np.log(1e12), n)) * rng.choice([-1.0, 1.0], n)
+    got = lg.leaf_batch("div", a, b, **kw).cpu().numpy().astype(L)
+    ref = a.astype(L) / b.astype(L)
+    assert float(np.max(np.abs(got - ref) / np.abs(ref))) <= 2.3e-16
+    assert float(lg.leaf_batch("div", [0.0], [3.0], **{k: v[:1] for k, v in kw.items()})[0]) == 0.0
+    x = np.concatenate([np.exp(rng.uniform(np.log(1e-12), np.log(1e12), n // 2)), 1.0 + rng.uniform(-0.3, 0.4, n // 2)])
+    got = lg.leaf_batch("log2_pairwise", x, **kw).cpu().numpy().astype(L)
+    ref = np.log2(x.astype(L))
+    assert float(np.max(np.abs(got - ref) / np.maximum(1.0, np.abs(ref)))) <= 5e-16
+    near = (np.abs(x - 1.0) < 0.4) & (x != 1.0)
+    assert float(np.max(np.abs(got[near] - ref[near]) / np.abs(ref[near]))) <= 5e-15
+    y = rng.uniform(-1000.0, 1000.0, n)
+    got = lg.leaf_batch("exp2_pairwise", y, **kw).cpu().numpy().astype(L)
+    ref = np.exp2(y.astype(L))
+    assert float(np.max(np.abs(got - ref) / ref)) <= 3e-16
+    xb = np.exp(rng.uniform(np.log(1e-8), np.log(1e8), n))
+    yb = rng.uniform(-6.0, 6.0, n)
+    got = lg.leaf_batch("pow_pairwise", xb, yb, **kw).cpu().numpy().astype(L)
+    ref = np.power(xb.astype(L), yb.astype(L))
+    assert float(np.max(np.abs(got - ref) / ref)) <= 5e-14

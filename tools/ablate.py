@@ -41,11 +41,7 @@ VARIANTS = {
     # mixed-precision kernels only (quick to build): experiments on geff_mixed, run with `ablate.py run mix`
     "mx_base": ["-DLGAR_ONLY_MIXED"], "mx_general": ["-DLGAR_ONLY_MIXED", "-DLGAR_GEFFM_GENERAL_ONLY"],
     "mx_regions": ["-DLGAR_ONLY_MIXED", "-DLGAR_COUNT_GEFFM_REGIONS"],
-    "mx_ieeediv": ["-DLGAR_ONLY_MIXED", "-DLGAR_IEEE_DIV"],
-    "mx_noheads": ["-DLGAR_ONLY_MIXED", "-DLGAR_NO_HEADS"], "mx_nodedupe": ["-DLGAR_ONLY_MIXED", "-DLGAR_NO_DEDUPE"],
-    "mx_neither": ["-DLGAR_ONLY_MIXED", "-DLGAR_NO_HEADS", "-DLGAR_NO_DEDUPE"],
-    "mx_estrin": ["-DLGAR_ONLY_MIXED", "-DLGAR_ESTRIN"],
-    "f32_only": ["-DLGAR_ONLY_F32"], "f32_noheads": ["-DLGAR_ONLY_F32", "-DLGAR_NO_HEADS_ARG"],
+    "f32_only": ["-DLGAR_ONLY_F32"], 
     "mx_occ1": ["-DLGAR_ONLY_MIXED", "-DLGAR_OCC_F64_SMALL=1"],
     "mx_occ1_ilp": ["-DLGAR_ONLY_MIXED", "-DLGAR_OCC_F64_SMALL=1", "-mllvm", "-amdgpu-sched-strategy=max-ilp"],
     "mx_ilp": ["-DLGAR_ONLY_MIXED", "-mllvm", "-amdgpu-sched-strategy=max-ilp"],
