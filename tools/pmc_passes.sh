@@ -27,6 +27,7 @@ run() {  # run NAME WORKLOAD rocprof-args...
   rm -rf /tmp/prof_$name
 }
 for wl in ${WORKLOADS:-f32 f64 tan mix}; do
+  echo "workload $wl: $(date +%T)"
   run stats $wl --stats
   run valu $wl --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VALU_TRANS_F32 SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES
   run mix $wl --pmc SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64
