@@ -648,10 +648,10 @@ def main():
                 es = lg.LgarEngine(Ps["alpha"], Ps["n"], Ps["ksat"], Ps["theta_e"], Ps["theta_r"], Ps["thickness"],
                                    dt_h=300.0 / 3600.0, ponded_depth_max=0.0, dtype=torch.float32, device=dev)
                 best = None
-                for _ in range(2):
+                for _ in range(3):  # (best of three: the reader's copying threads share the host with everything else)
                     es.reset()
                     st = {}
-                    run_streamed_columns(es, mm, None, chunk=96, series=("runoff",), check=False, stats=st)
+                    run_streamed_columns(es, mm, None, chunk=96, series=("runoff",), check=False, stats=st, reader_threads=4)
                     if best is None or st["wall_s"] < best["wall_s"]:
                         best = st
                 del mm, es
@@ -660,7 +660,7 @@ def main():
                 subs["streamed_host_forcing"] = {
                     "value": best["column_timesteps_per_s"], "unit": "column-timesteps/s (host -> device included)",
                     "host_to_device_GBps": best["host_to_device_GBps"], "bytes_host_to_device": best["bytes_host_to_device"],
-                    "wall_ms": 1e3 * best["wall_s"], "columns": Ns, "timesteps": Ts, "chunk_rows": best["chunk_rows"], "dtype": "f32",
+                    "wall_ms": 1e3 * best["wall_s"], "columns": Ns, "timesteps": Ts, "chunk_rows": best["chunk_rows"], "reader_threads": best["reader_threads"], "dtype": "f32",
                     "kernel_appetite_GBps_at_1e10": best["kernel_appetite_GBps_at_1e10"],
                     "workload": "[T, N] precipitation with N distinct columns in a memory-mapped file (tmpfs), PET zero: reader "
                                 "thread -> pinned double buffer -> HBM on a side stream -> lgar_forward per chunk; bound by the "
