@@ -156,21 +156,36 @@ def run_streamed_columns(engine, precip, pet=None, chunk=256, series=("runoff",)
         for f in futs:
             f.result()
 
+    stop = threading.Event()  # set when the consumer gives up (an exception below): the reader must not wait for ever
+
     def reader():
         try:
             for ci, (lo, hi) in enumerate(bounds):
                 b = ci % 2
-                pinned_free[b].acquire()  # the copy that last read this pinned buffer has finished (released below)
+                while not pinned_free[b].acquire(timeout=0.2):  # the copy that last read this pinned buffer has finished
+                    if stop.is_set():
+                        return
+                if stop.is_set():
+                    return
                 h = pinned[b].numpy()
                 copy_rows(h[0], precip, lo, hi)
                 if pet_kind == "full":
                     copy_rows(h[1], pet, lo, hi)
                 elif pet_kind == "basin":
                     pinned_pet[b].numpy()[: hi - lo, 0] = pet[lo:hi]
-                filled.put(ci)
+                while True:
+                    try:
+                        filled.put(ci, timeout=0.2)
+                        break
+                    except queue.Full:
+                        if stop.is_set():
+                            return
         except Exception as e:  # noqa: BLE001 -- handed to the consumer, which re-raises
             err.append(e)
-            filled.put(-1)
+            try:
+                filled.put(-1, timeout=1.0)
+            except queue.Full:
+                pass
 
     th = threading.Thread(target=reader, daemon=True)
     outs = {nm: [] for nm in series}
@@ -181,7 +196,13 @@ def run_streamed_columns(engine, precip, pet=None, chunk=256, series=("runoff",)
     pending_release = []  # (event, pinned index): released to the reader once the copy has finished
 
     def upload(ci):
-        got = filled.get()
+        while True:
+            try:
+                got = filled.get(timeout=0.5)
+                break
+            except queue.Empty:
+                if not th.is_alive():
+                    raise (err[0] if err else RuntimeError("the forcing reader ended before chunk %d" % ci))
         if got < 0:
             raise err[0]
         lo, hi = bounds[ci]
@@ -210,26 +231,29 @@ def run_streamed_columns(engine, precip, pet=None, chunk=256, series=("runoff",)
             ev.synchronize()
             pinned_free[b].release()
 
-    if bounds:
-        upload(0)
-    for ci, (lo, hi) in enumerate(bounds):
-        if ci + 1 < len(bounds):
-            release_finished(block=True)  # the reader may refill the pinned buffer the previous upload has drained
-            upload(ci + 1)
-        b, n = ci % 2, hi - lo
-        main.wait_event(ready[b])
-        if reduce_basin:
-            out = engine.forward(bufs[b][0][:n], bufs[b][1][:n], series=(), basin=series, weights=weights, check=False)
-        else:
-            out = engine.forward(bufs[b][0][:n], bufs[b][1][:n], series=series, check=False)
-        freed[b].record(main)
-        for nm in series:
-            outs[nm].append(all_reduce_sum(out["basin:" + nm]) if reduce_basin else out[nm])
-    release_finished(block=True)
-    th.join()
-    if pool is not None:
-        pool.shutdown(wait=True)
-    torch.cuda.synchronize(dev)
+    try:
+        if bounds:
+            upload(0)
+        for ci, (lo, hi) in enumerate(bounds):
+            if ci + 1 < len(bounds):
+                release_finished(block=True)  # the reader may refill the pinned buffer the previous upload has drained
+                upload(ci + 1)
+            b, n = ci % 2, hi - lo
+            main.wait_event(ready[b])
+            if reduce_basin:
+                out = engine.forward(bufs[b][0][:n], bufs[b][1][:n], series=(), basin=series, weights=weights, check=False)
+            else:
+                out = engine.forward(bufs[b][0][:n], bufs[b][1][:n], series=series, check=False)
+            freed[b].record(main)
+            for nm in series:
+                outs[nm].append(all_reduce_sum(out["basin:" + nm]) if reduce_basin else out[nm])
+        release_finished(block=True)
+    finally:  # whatever happened: the reader and its copying threads end, and nothing still reads the pinned buffers
+        stop.set()
+        th.join()
+        if pool is not None:
+            pool.shutdown(wait=True)
+        torch.cuda.synchronize(dev)
     wall = time.perf_counter() - t0
     if stats is not None:
         moved = T * N * n_full * (4 if src_dt == torch.float32 else 8)

@@ -200,6 +200,17 @@ def test_streamed_per_column_forcing_from_a_mapped_file_equals_single_shot(tmp_p
     with pytest.raises(ValueError):
         run_streamed_columns(mk(), pr[:, :5], None)
 
+    class FailingSource:  # a forcing source whose read fails part way (a truncated file, an I/O error): surfaces, never hangs
+        ndim, shape, dtype = 2, pr.shape, pr.dtype
+
+        def __getitem__(self, sl):
+            if sl.start >= 300:
+                raise OSError("read failed at row %d" % sl.start)
+            return pr[sl]
+
+    with pytest.raises(OSError, match="read failed"):
+        run_streamed_columns(mk(), FailingSource(), None, chunk=97, series=("runoff",), check=False)
+
 
 def test_in_kernel_basin_aggregation():
     """LgarStepOut.basin: per-step basin sums reduced in the kernel epilogue (wave reduction + fp64 atomics) equal the
