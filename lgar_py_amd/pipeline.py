@@ -80,6 +80,31 @@ def write_forcing_file(path, array):
     return path
 
 
+def forcing_csvs_to_files(csv_paths, precip_path, pet_path, nsteps=None, dtype="float32", mm_to_cm=0.1):
+    """One forcing file per column in the reference's on-disk formats (`Time,P(mm/h),PET(mm/h)` CSV or the `#Time` variant of
+    the synth files: data.read_forcing, data/Data.py:32-37) -> the two row-major [T, N] files run_streamed_columns maps
+    (cm/h): column c is csv_paths[c].  The files are written column by column through a memory map, so N x T never has to fit
+    in memory; every file must hold at least `nsteps` rows (default: the length of the first).  Returns (T, N)."""
+    import numpy as np
+
+    from .data import read_forcing
+    if not csv_paths:
+        raise ValueError("no forcing files given")
+    _, x0 = read_forcing(csv_paths[0], nsteps, mm_to_cm)
+    T, N = x0.shape[0], len(csv_paths)
+    outs = [np.lib.format.open_memmap(p_, mode="w+", dtype=np.dtype(dtype), shape=(T, N)) for p_ in (precip_path, pet_path)]
+    for c, path in enumerate(csv_paths):
+        x = x0 if c == 0 else read_forcing(path, T, mm_to_cm)[1]
+        if x.shape[0] < T:
+            raise ValueError("%s holds %d forcing rows, %d are needed" % (path, x.shape[0], T))
+        outs[0][:, c] = x[:T, 0]
+        outs[1][:, c] = x[:T, 1]
+    for o in outs:
+        o.flush()
+    del outs
+    return T, N
+
+
 def open_forcing_file(path):
     """Memory-map a file written by write_forcing_file (numpy .npy container, row-major [T, N]): pages are read when a chunk
     is staged, never the whole file."""

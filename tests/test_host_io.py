@@ -2,6 +2,7 @@
 import os
 
 import numpy as np
+import pytest
 
 from conftest import GOLDEN
 
@@ -56,3 +57,31 @@ def test_soil_table_and_forcing_readers(tmp_path):
     _, x2 = D.read_forcing(p, nsteps=10)
     assert x2.shape == (10, 2)
     assert abs(D.calculate_nse(np.array([1.0, 2.0, 3.0]), np.array([1.0, 2.0, 3.0])) - 1.0) < 1e-15
+
+
+def test_forcing_csvs_to_mapped_files(tmp_path):
+    """pipeline.forcing_csvs_to_files: one CSV per column in the reference's two on-disk formats -> the [T, N] files that
+    run_streamed_columns maps (mm/h -> cm/h, data/Data.py:37); short files are refused."""
+    from lgar_py_amd.pipeline import forcing_csvs_to_files, open_forcing_file
+    rng = np.random.default_rng(0)
+    T, N = 30, 5
+    P, E = rng.uniform(0, 20, (T, N)), rng.uniform(0, 1, (T, N))
+    paths = []
+    for c in range(N):
+        p = tmp_path / ("col%d.csv" % c)
+        with open(p, "w") as f:
+            f.write(("#Time" if c % 2 else "Time") + ",P(mm/h),PET(mm/h)\n")
+            for t in range(T):
+                f.write("2020-01-01 %02d:00:00,%r,%r\n" % (t % 24, float(P[t, c]), float(E[t, c])))
+            if c % 2:
+                f.write("\n\n")  # the synth files end in blank lines
+        paths.append(str(p))
+    got = forcing_csvs_to_files(paths, str(tmp_path / "p.npy"), str(tmp_path / "e.npy"), nsteps=24, dtype="float64")
+    assert got == (24, N)
+    fp, fe = open_forcing_file(str(tmp_path / "p.npy")), open_forcing_file(str(tmp_path / "e.npy"))
+    assert isinstance(fp, np.memmap) and fp.shape == (24, N)
+    assert np.allclose(fp, P[:24] * 0.1, rtol=0, atol=1e-15) and np.allclose(fe, E[:24] * 0.1, rtol=0, atol=1e-15)
+    with open(paths[2], "w") as f:
+        f.write("Time,P(mm/h),PET(mm/h)\n2020-01-01 00:00:00,1.0,0.1\n")
+    with pytest.raises(ValueError, match="forcing rows"):
+        forcing_csvs_to_files(paths, str(tmp_path / "p2.npy"), str(tmp_path / "e2.npy"))
