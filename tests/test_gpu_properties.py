@@ -263,3 +263,32 @@ def test_lean_division_and_pairwise_polynomials_on_hardware():
     got = lg.leaf_batch("pow_pairwise", xb, yb, **kw).cpu().numpy().astype(L)
     ref = np.power(xb.astype(L), yb.astype(L))
     assert float(np.max(np.abs(got - ref) / ref)) <= 5e-14
+
+
+@pytest.mark.parametrize("which", ["f32", "f64", "mixed"])
+def test_the_same_job_twice_is_bit_identical(which):
+    """Run-to-run determinism of the forward kernels (persistent waves pull their 64-column blocks in whatever order the
+    hardware grants the tickets): the same 262 144-column job twice gives the same status words, series and front tables bit
+    for bit.  Round 4 met two builds of the fp32 kernel that did not (an address-taken local array; a variant with 54 spilled
+    registers) -- the replica tests above catch that too, this one says it in so many words."""
+    import lgar_py_amd as lg
+    from lgar_py_amd import workloads as W
+    N = 1 << 18
+    dt = torch.float32 if which == "f32" else torch.float64
+    kw = dict(geff_precision="f32") if which == "mixed" else {}
+    P = W.perturbed_columns(N, seed=0)
+    sc = torch.tensor(W.forcing_scale(N, seed=1000), device="cuda")
+    f = W.synth1_forcing()
+    eng = lg.LgarEngine(P["alpha"], P["n"], P["ksat"], P["theta_e"], P["theta_r"], P["thickness"], dt_h=300.0 / 3600.0,
+                        ponded_depth_max=0.0, dtype=dt, **kw)
+    pr = (torch.tensor(f[:, 0], device="cuda")[:, None] * sc[None, :]).to(dt).contiguous()
+    pe = torch.zeros_like(pr)
+    runs = []
+    for _ in range(3):
+        eng.reset()
+        o = eng.forward(pr, pe, series=("runoff", "infiltration"), check=False)
+        runs.append((eng.status.clone(), o["runoff"].clone(), o["infiltration"].clone(), eng.theta.clone(), eng.depth.clone(),
+                     eng.totals.clone()))
+    for r in runs[1:]:
+        for a, b in zip(runs[0], r):
+            assert torch.equal(torch.nan_to_num(a.double(), nan=-1.0), torch.nan_to_num(b.double(), nan=-1.0))
