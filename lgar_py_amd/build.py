@@ -21,7 +21,10 @@ HEADERS = ["lgar_device.hpp", "lgar_dual.hpp", "lgar_math.hpp", "lgar_host.hpp",
 # fp32 division stays correctly rounded: with the rcp-based fast divide x/x != 1, Se = (theta-theta_r)/(theta_e-theta_r)
 # exceeds 1 at saturation and 8 % of perturbed columns fault (measured), for no speed gain.
 # -munsafe-fp-atomics: atomicAdd(double*) is one global_atomic_add_f64, not a compare-and-swap loop
-FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-munsafe-fp-atomics", "-fPIC", "-shared", "-std=c++17", "-Wno-pass-failed"]
+# -Os, not -O3: the kernels are 10-25 thousand instructions each and eight waves of a CU sit at eight different places in them;
+# the size-minded build is 3-4 % faster in fp32, 3 % in the mixed mode, 1-2 % elsewhere (same-box A/B of the whole library,
+# profiles/r04/mixed_kernel_experiments.jsonl) -- it unrolls and duplicates less, and spills fewer registers (fp32: 31 vs 37)
+FLAGS = ["--offload-arch=gfx950", "-Os", "-ffp-contract=off", "-munsafe-fp-atomics", "-fPIC", "-shared", "-std=c++17", "-Wno-pass-failed"]
 JOBS = int(os.environ.get("LGAR_BUILD_JOBS", "0")) or min(8, os.cpu_count() or 4)
 
 

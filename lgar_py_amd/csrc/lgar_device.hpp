@@ -882,8 +882,11 @@ __device__ __forceinline__ double geff_mixed_core(const LayerK<double> &l, doubl
   const bool outside = is_nan(h_i) || is_nan(h_f);
   return outside ? res + (h_i + h_f) : res;
 }
-// calc_geff(theta1 -> theta2) in the mixed-precision mode: heads and end nodes from the two water contents (mixed_end)
-__device__ __forceinline__ double geff_mixed(const LayerK<double> &l, double theta1, double theta2, int nint) {
+// calc_geff(theta1 -> theta2) in the mixed-precision mode: heads and end nodes from the two water contents (mixed_end).
+// NOT inlined: its callers are the two call sites that run rarely (insert_water on a memo miss: 16 % of the wave-level
+// evaluations; the dry-depth evaluation: 1 %) -- calc_dzdt, the hot one, has its own inlined copy (geff_mixed_heads).  Two fewer
+// copies of the trapezoid in the kernel: 93 -> 52 spilled registers, and the size of the code is part of its speed (build.py).
+__device__ __attribute__((noinline)) double geff_mixed(const LayerK<double> &l, double theta1, double theta2, int nint) {
   const double se_i = se_from_theta(l, theta1);
   const double se_f = se_from_theta(l, theta2);
   // K_r at Se == 1 (the 1e-12 nudge of calc_k_from_se): (1 - (1e-12)^m)^2
