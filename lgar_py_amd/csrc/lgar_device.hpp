@@ -54,6 +54,12 @@ __device__ __forceinline__ bool first_active_lane() {
   const unsigned long long m = __ballot(1);
   return (int)(threadIdx.x & 63u) == __ffsll((long long)m) - 1;
 }
+// between the stores and the loads of an exchange through the wave's LDS (cooperating lanes): one wave = one workgroup and a
+// wave's LDS operations complete in order, so this only pins the compiler
+__device__ __forceinline__ void lds_exchange_point() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
 #else  // tests/devsim: the same device code compiled for the host, one lane at a time (test infrastructure only)
 __device__ __forceinline__ float lg2(float x) { return log2f(x); }
 __device__ __forceinline__ float ex2(float x) { return exp2f(x); }
@@ -61,6 +67,7 @@ __device__ __forceinline__ float sq(float x) { return sqrtf(x); }
 __device__ __forceinline__ float clamp01(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
 __device__ __forceinline__ unsigned long long any_lane(bool p) { return p ? 1ull : 0ull; }
 __device__ __forceinline__ bool first_active_lane() { return true; }
+__device__ __forceinline__ void lds_exchange_point() {}
 #endif
 __device__ __forceinline__ float pw(float x, float y) { return ex2(y * lg2(x)); }
 // EX = true (verification mode, double precision only): the correctly rounded library pow, as the reference's torch.pow;
@@ -323,60 +330,143 @@ __device__ __forceinline__ void geff_shared_blocks(const LayerK<S> &l, const S &
 // The trapezoid's interior for COOPERATING lanes (forward kernels on jobs too small to fill the chip, LgarDims.forward_lanes):
 // the `lanes` lanes of an aligned group all carry the SAME column -- same values, same branches.  `tab` is the group's table
 // of LGAR_COOP_TAB doubles in LDS.
-//   1. every lane runs the plain loop's running sum h2 += dh and leaves head j in tab[j] (the lanes of a group store the same
-//      value to the same address);
-//   2. lane r evaluates nodes r, r + lanes, r + 2 lanes, ... -- two at a time, as the plain loop does -- and puts K(head) where
-//      the head was (no other lane reads that head);
-//   3. every lane adds the nodes up in order.
-// Heads, node values and the sum are those of the plain loop bit for bit: each node goes through the same operations on the
+//   1. the group's first lane runs the plain loop's running sum h2 += dh and leaves head j in tab[j];
+//   2. lane r evaluates nodes r, r + lanes, r + 2 lanes, ... -- two or four at a time -- and puts K(head) where the head was
+//      (no other lane reads that head);
+//   3. lane r turns its nodes into the trapezoid's terms (K_{j-1} + K_j) dh/2, in place;
+//   4. every lane adds the 120 terms up in order.
+// Heads, node values, terms and the sum are those of the plain loop bit for bit: each goes through the same operations on the
 // same operands, only once per group instead of once per lane.
 #define LGAR_COOP_TAB 128      /* most trapezoid intervals a cooperating job may have (LgarDims.nint; 120 in every bundled config) */
 #define LGAR_COOP_TAB_ROW 130  /* doubles per group's table in LDS: padded so that the groups' tables start on different banks */
 // (r: my place in the group.  The last group of a wavefront also takes the lanes left over when `lanes` does not divide 64:
 // their r >= lanes; they evaluate no node -- a node's table slot must be read as a head and rewritten by ONE lane -- and take
 // part in everything else.)
+// W nodes per lane and round (independent chains of ~100 dependent double-precision operations each: one wave alone on its SIMD
+// issues a dependent operation every ~10 cycles, so the chains of a round overlap)
+template <int W>
+__device__ __forceinline__ void geff_coop_node_rounds(const LayerK<double> &l, double nm1, double half_m, double k_sat1, double k_first,
+                                                      double hdh, int nint, int lanes, double *tab, int r) {
+  const int stride = W * lanes;
+  for (int first = 0; first < nint; first += stride) {
+    double h[W], k[W];
+    bool ok[W];
+#pragma unroll
+    for (int u = 0; u < W; u++) {
+      const int j = first + r + u * lanes;
+      ok[u] = (r < lanes) && (j < nint);
+      h[u] = tab[ok[u] ? j : 0];
+    }
+#pragma unroll
+    for (int u = 0; u < W; u++) k[u] = geff_node(l, nm1, half_m, h[u]);
+#pragma unroll
+    for (int u = 0; u < W; u++) {
+      k[u] = (fabs(h[u]) < 0.1 || h[u] < 0.0) ? k_sat1 : k[u];  // utils.py:124-128 (never true on the nodes the plain loop leaves unchecked)
+      if (ok[u]) tab[first + r + u * lanes] = k[u];
+    }
+  }
+  lds_exchange_point();
+  LGAR_MEASURE_POINT(CLK, 14)
+  // the trapezoid's terms (K_{j-1} + K_j) dh/2, in place: the rounds run from the LAST to the first, so that a round only
+  // overwrites nodes no later round reads (its own, whose predecessors belong to it or to a round still to come)
+  for (int first = ((nint - 1) / stride) * stride; first >= 0; first -= stride) {
+    double p[W], k[W];
+    bool ok[W];
+#pragma unroll
+    for (int u = 0; u < W; u++) {
+      const int j = first + r + u * lanes;
+      ok[u] = (r < lanes) && (j < nint);
+      p[u] = tab[(ok[u] && j > 0) ? j - 1 : 0];
+      k[u] = tab[ok[u] ? j : 0];
+    }
+    lds_exchange_point();  // every lane has its operands before any term replaces a node
+#pragma unroll
+    for (int u = 0; u < W; u++) {
+      const int j = first + r + u * lanes;
+      if (ok[u]) tab[j] = (((j > 0) ? p[u] : k_first) + k[u]) * hdh;
+    }
+  }
+}
 __device__ __forceinline__ void geff_nodes_cooperative(const LayerK<double> &l, double nm1, double half_m, double k_sat1, double &h2,
                                                        double dh, double hdh, double &g, double &k1, int nint, int lanes, double *tab, int r) {
   // one wave = one workgroup: LDS operations of a wave complete in order, the fences only pin the compiler
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // (earlier loads of the table stay in front of these stores)
-  for (int j = 0; j < nint; j++) {
-    tab[j] = h2;  // (the lanes of a group store the same value to the same address; predicating the store on one lane was
-    h2 = h2 + dh; //  measured SLOWER: 72 -> 92 ms for one column)
-  }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  for (int ja = (r < lanes) ? r : nint; ja < nint; ja += 2 * lanes) {
-    const int jb = ja + lanes;
-    const bool two = jb < nint;
-    const double ha = tab[ja], hb = tab[two ? jb : ja];
-    double ka = geff_node(l, nm1, half_m, ha);
-    double kb = geff_node(l, nm1, half_m, hb);
-    ka = (fabs(ha) < 0.1 || ha < 0.0) ? k_sat1 : ka;  // utils.py:124-128 (never true on the nodes the plain loop leaves unchecked)
-    kb = (fabs(hb) < 0.1 || hb < 0.0) ? k_sat1 : kb;
-    tab[ja] = ka;
-    if (two) tab[jb] = kb;
-  }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  // (eight LDS reads in flight at a time: one wave alone on its SIMD has nothing else to cover their latency)
-  int q0 = 0;
-  for (; q0 + 8 <= nint; q0 += 8) {
-    double kq[8];
+  // 1. the heads: a chain of nint dependent additions; ONE lane of the group runs it (64 lanes storing to one address are
+  //    64 conflicting writes: 24 cycles per head, measured)
+  if (r == 0) {
+    double h = h2;
+    int j = 0;
+    for (; j + 16 <= nint; j += 16) {
+      // (sixteen heads in registers of their own, then their stores: an addition that overwrites a register a store still
+      // reads waits for that store)
+      double hh[16];
 #pragma unroll
-    for (int j = 0; j < 8; j++) kq[j] = tab[q0 + j];  // same address in every lane of the group: a broadcast
+      for (int u = 0; u < 16; u++) {
+        hh[u] = h;
+        h = h + dh;
+      }
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-      g = g + ((k1 + kq[j]) * hdh);
-      k1 = kq[j];
+      for (int u = 0; u < 16; u++) tab[j + u] = hh[u];
+    }
+    for (; j < nint; j++) {
+      tab[j] = h;
+      h = h + dh;
     }
   }
-  for (; q0 < nint; q0++) {
-    const double kq = tab[q0];
-    g = g + ((k1 + kq) * hdh);
-    k1 = kq;
+  lds_exchange_point();
+  LGAR_MEASURE_POINT(CLK, 13)
+  // 2. nodes, 3. terms: two per lane and round, four when that still leaves several rounds
+  if (nint > 4 * lanes) geff_coop_node_rounds<4>(l, nm1, half_m, k_sat1, k1, hdh, nint, lanes, tab, r);
+  else geff_coop_node_rounds<2>(l, nm1, half_m, k_sat1, k1, hdh, nint, lanes, tab, r);
+  lds_exchange_point();
+  LGAR_MEASURE_POINT(CLK, 15)
+  // 4. every lane adds the terms up in order (the same address in every lane of the group: a broadcast).  The additions are
+  //    one dependent chain; the reads of the next sixteen terms are in flight while the chain works through the present ones.
+  {
+    const int nb = nint >> 4;  // batches of sixteen terms, alternately in two sets of registers
+    const double *tail = tab + (nb << 4);
+    double ta[16], tb[16], tc[8];
+    if (nb > 0) {
+#pragma unroll
+      for (int j = 0; j < 16; j++) ta[j] = tab[j];
+    }
+    if (nint & 8) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) tc[j] = tail[j];
+    }
+#pragma unroll
+    for (int i = 0; i < LGAR_COOP_TAB / 16; i++) {
+      if (i < nb) {
+        const double *next = tab + 16 * (i + 1);
+        // (the next batch is read whether it exists or not -- unconditional loads keep the waits exact; the table has
+        // LGAR_COOP_TAB_ROW >= 16 (i + 2) entries for every i that gets here with another batch to come)
+        if (i & 1) {
+          if (i + 1 < LGAR_COOP_TAB / 16) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) ta[j] = next[j];
+          }
+#pragma unroll
+          for (int j = 0; j < 16; j++) g = g + tb[j];
+        } else {
+          if (i + 1 < LGAR_COOP_TAB / 16) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) tb[j] = next[j];
+          }
+#pragma unroll
+          for (int j = 0; j < 16; j++) g = g + ta[j];
+        }
+      }
+    }
+    int q0 = nb << 4;
+    if (nint & 8) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) g = g + tc[j];
+      q0 += 8;
+    }
+    for (; q0 < nint; q0++) g = g + tab[q0];
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // the next call's stores stay behind these loads
-  __builtin_amdgcn_wave_barrier();
+  lds_exchange_point();  // the next call's stores stay behind these loads
+  LGAR_MEASURE_POINT(CLK, 16)
 }
 #endif
 #ifndef LGAR_DEVSIM
@@ -385,30 +475,53 @@ __device__ __forceinline__ void geff_nodes_cooperative(const LayerK<double> &l, 
 // "pow, offset from 1, nudge, pow, finish": the lanes run ONE instruction stream with their own exponents and pick their own
 // finish, every value going through exactly the operations h_from_se / k_from_se apply to it (bit-identical results; the
 // serial chain of eight pows becomes one of two).
+// Riders (calc_dzdt): up to LGAR_LMAX more conductivities K(Se) of OTHER evaluations -- the moving front's own K(theta) and the
+// K of every layer above at the front's psi (calc_bottom_sum, Layer.py:1557-1582) -- are the same "pow, offset, nudge, pow,
+// finish": lane 4 + e of the group takes rider e, with that rider's layer (xl) and Se (xse) as ITS operands, and every lane
+// reads the n_riders results back into xk before the table is reused for the trapezoid's heads.
+struct CoopRiders {
+  int n = 0;           // riders of this call (the group needs 4 + n lanes)
+  LayerK<double> l;    // MY rider's layer and Se (lanes 4 .. 4 + n - 1; anything elsewhere)
+  double se = 1.0;
+  double k[LGAR_LMAX]; // out: K of rider e
+};
 __device__ __forceinline__ void geff_ends_cooperative(const LayerK<double> &l, double se_i, double se_f, double &h_i, double &h_f,
-                                                      double &k_i, double &k_sat1, double *xchg, int r) {
-  const int which = r & 3;  // 0: h(Se_i), 1: h(Se_f), 2: K(Se_i), 3: K(1)
+                                                      double &k_i, double &k_sat1, double *xchg, int r, CoopRiders *rd = nullptr) {
+  const bool rider = (rd != nullptr) && (r >= 4) && (r - 4 < rd->n);
+  const int which = rider ? 2 : (r & 3);  // 0: h(Se_i), 1: h(Se_f), 2: K(Se_i), 3: K(1)
   const bool is_h = which < 2;
-  const double se = (which == 1) ? se_f : ((which == 3) ? 1.0 : se_i);
-  const double sp = pw(se, is_h ? -l.inv_m : l.inv_m);
+  double se = (which == 1) ? se_f : ((which == 3) ? 1.0 : se_i);
+  double inv_m = l.inv_m, m = l.m, ksat = l.ksat;
+  if (rd != nullptr) {
+    se = rider ? rd->se : se;
+    inv_m = rider ? rd->l.inv_m : inv_m; m = rider ? rd->l.m : m; ksat = rider ? rd->l.ksat : ksat;
+  }
+  const double sp = pw(se, is_h ? -inv_m : inv_m);
   double base = is_h ? sp - 1.0 : 1.0 - sp;
   if (fabs(base) <= 1e-8) base = base + 1e-12;
-  const double op = pw(base, is_h ? l.inv_n : l.m);
+  const double op = pw(base, is_h ? l.inv_n : m);
   const double t = 1.0 - op;
-  const double mine = is_h ? (1.0 / l.alpha) * op : l.ksat * sqrt(se) * (t * t);
+  const double mine = is_h ? (1.0 / l.alpha) * op : ksat * sqrt(se) * (t * t);
   double *grp = xchg;  // the group's table
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   if (r < 4) grp[which] = mine;  // lanes 0..3 of the group (a group has at least 4)
+  if (rider) grp[r] = mine;
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   __builtin_amdgcn_wave_barrier();
   h_i = grp[0]; h_f = grp[1]; k_i = grp[2]; k_sat1 = grp[3];
+  if (rd != nullptr) {
+#pragma unroll
+    for (int e = 0; e < LGAR_LMAX; e++) rd->k[e] = grp[4 + e];  // (slots past the last rider: stale values nobody uses)
+  }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   __builtin_amdgcn_wave_barrier();
 }
+#else
+struct CoopRiders { int n = 0; LayerK<double> l; double se = 1.0; double k[LGAR_LMAX]; };
 #endif
 template <typename S>
 __device__ __forceinline__ S geff_fused(const LayerK<S> &l, S theta1, S theta2, int nint, real_t<S> *xchg = nullptr, int coop = 0,
-                                        int rank = 0) {
+                                        int rank = 0, CoopRiders *riders = nullptr) {
   using R = real_t<S>;
   const S se_i = se_from_theta(l, theta1);
   const S se_f = se_from_theta(l, theta2);
@@ -417,7 +530,9 @@ __device__ __forceinline__ S geff_fused(const LayerK<S> &l, S theta1, S theta2, 
 #ifndef LGAR_DEVSIM
   if constexpr (sizeof(S) == 8 && sizeof(R) == 8) {
     if (coop >= 4 && xchg != nullptr) {
-      geff_ends_cooperative(l, se_i, se_f, h_i, h_f, k1, k_sat1, xchg, rank);
+      LGAR_MEASURE_POINT(CLK, 11)
+      geff_ends_cooperative(l, se_i, se_f, h_i, h_f, k1, k_sat1, xchg, rank, riders);
+      LGAR_MEASURE_POINT(CLK, 12)
       ends_done = true;
     }
   }
@@ -995,6 +1110,7 @@ template <typename R> struct Glob {
 // lanes (LGAR_COOP_GROUPS slots: the lanes of a group hold the same column, read the same address -- an LDS broadcast -- and
 // write the same value to it), which is what lets a 32-front table of such a wave fit four waves per CU.
 #define LGAR_COOP_GROUPS 16
+constexpr bool coop_mode(int mode) { return mode == 4; }
 template <typename S, int FMAX, int STRIDE = WAVE> struct FrontsView {
   S *base;             // &lds.f[0][0][slot]
   unsigned char *fl;   // &lds.fl[0][slot]
@@ -1028,7 +1144,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
   // torch.pow); the plain-float fast mode divides by reciprocal; everything else is lean pow + IEEE division
   // (3: MODE 3, the mixed-precision kernels -- lean pow with pairwise-combined polynomials, see fast_pow)
   static constexpr int POL = ((MODE == 0) && (sizeof(R) == 8)) ? 1 : (((MODE != 0) && (sizeof(S) == 4)) ? 2 : ((MODE == 3 && sizeof(S) == 8) ? 3 : 0));
-  static constexpr int STRIDE = (MODE == 4) ? LGAR_COOP_GROUPS : WAVE;  // front-table slots per row (see FrontsView)
+  static constexpr int STRIDE = coop_mode(MODE) ? LGAR_COOP_GROUPS : WAVE;  // front-table slots per row (see FrontsView)
   const ColParams<S, NL> &P;
   const LGAR_KARG Glob<R> *G;  // run-time constants, in the kernarg segment (re-pointed by the kernel's time loop)
   FrontsView<S, FMAX, STRIDE> F;
@@ -1061,8 +1177,8 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
 
   __device__ __forceinline__ S cum_at(int k) const { return sel<S, NL>(P.cum, k); }
   // calc_geff (lgar/green_ampt.py:19-99): trapezoid or closed form, per cfg.data.use_closed_form_G
-  __device__ __forceinline__ S capillary_drive(const LayerK<S> &lk, S theta1, S theta2, int site = 0) {
-    (void)site;
+  __device__ __forceinline__ S capillary_drive(const LayerK<S> &lk, S theta1, S theta2, int site = 0, CoopRiders *riders = nullptr) {
+    (void)site; (void)riders;
     LGAR_MEASURE_POINT(NOGEFF, lk, theta1, theta2)
     LGAR_COUNT_GEFF_CALL(site)
     LGAR_MEASURE_POINT(DUP_GEFF, lk, theta1, theta2)
@@ -1073,8 +1189,8 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
     if constexpr (sizeof(S) != sizeof(R) && sizeof(R) == 8 && MODE != 0) {
       if (share_lanes >= 2 && !G->closed_form) return geff_fused<S>(lk, theta1, theta2, G->nint, xchg, share_lanes);
     }
-    if constexpr (MODE == 4 && sizeof(S) == 8 && sizeof(R) == 8) {  // plain double: cooperating lanes (small jobs)
-      if (share_lanes > 1 && !G->closed_form) return geff_fused<S>(lk, theta1, theta2, G->nint, xchg, share_lanes, coop_rank);
+    if constexpr (coop_mode(MODE) && sizeof(S) == 8 && sizeof(R) == 8) {  // plain double: cooperating lanes (small jobs)
+      if (share_lanes > 1 && !G->closed_form) return geff_fused<S>(lk, theta1, theta2, G->nint, xchg, share_lanes, coop_rank, riders);
     }
     if constexpr (MODE == 3 && sizeof(S) == 8 && sizeof(R) == 8) {  // plain double, LgarDims.geff_mode = 1
       if (!G->closed_form) return geff_mixed(lk, theta1, theta2, G->nint);
@@ -1163,30 +1279,91 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
   // found by a bracketed Newton iteration (5-8 mass evaluations) instead of the reference's fixed-step decimal
   // search (58-82 on average, Layer.py:275-317).  theta differs from the literal search by <= tolerance / thickness.
   // Gradient semantics (dual numbers): psi_final = psi_init + constant, as in the reference (Layer.py:277-288).
+  // Cooperating lanes (MODE 4: the lanes of a group carry the SAME column): a mass evaluation is K + 1 independent
+  // theta(psi) -- two pows each -- so lane r of the group evaluates layer min(r, K) with that layer's parameters as its
+  // operands (ONE instruction stream) and the group exchanges the results through its LDS table; the sums are formed from
+  // them in the serial order.  Every value goes through exactly the operations of the serial evaluation: bit-identical.
+  static constexpr bool COOP = coop_mode(MODE) && (sizeof(S) == 8) && (sizeof(R) == 8);
+  // ... and what the group evaluated together BEFORE a search (coop_sweep_thetas): theta and d theta / d psi of the layers
+  // above and of the front's own layer at the front's psi -- the search's first mass evaluation
+  struct FirstEval {
+    bool have = false;
+    R th[NL], dth[NL], thk, dthk;
+  };
+
   template <int K>
   __device__ __forceinline__ S theta_mass_balance_newton(const LayerK<S> &lk, S psi0, S new_mass, S prior_mass,
-                                                         const S (&dth)[NL], const S (&dthick)[NL], S dth_k, S dthick_k) {
+                                                         const S (&dth)[NL], const S (&dthick)[NL], S dth_k, S dthick_k,
+                                                         const FirstEval &fe) {
     const R prior = val(prior_mass);
     R psi = val(psi0);
     R f = val(new_mass) - prior;
     if (ab(f) <= Tol<R>::mass) return theta_from_h<S, POL>(lk, psi0);
     R M = R(0.0), dM = R(0.0);
+    // my share of a mass evaluation (cooperating lanes): layer c_q's parameters
+    R c_al = val(lk.alpha), c_n = val(lk.n), c_m = val(lk.m), c_te = val(lk.te), c_tr = val(lk.tr);
+    int c_q = K;
+    bool together = false;
+    R last_x = R(-1.0), last_th = R(0.0);  // (cooperating lanes) the own layer's theta of the latest mass evaluation, and its psi
+    if constexpr (COOP && K > 0) {
+      together = share_lanes > K;
+      c_q = coop_rank < K ? coop_rank : K;
+#pragma unroll
+      for (int j = 0; j < K; j++) {
+        const bool mine = c_q == j;
+        c_al = choose(mine, val(P.alpha[j]), c_al); c_n = choose(mine, val(P.n[j]), c_n); c_m = choose(mine, val(P.m[j]), c_m);
+        c_te = choose(mine, val(P.te[j]), c_te); c_tr = choose(mine, val(P.tr[j]), c_tr);
+      }
+    }
+    auto sums = [&](R thk, R dthk, const R (&tj)[NL], const R (&dj)[NL]) {
+      M = val(dthick_k) * (thk - val(dth_k));
+      dM = val(dthick_k) * dthk;
+#pragma unroll
+      for (int j = 0; j < K; j++) {
+        M += val(dthick[j]) * (tj[j] - val(dth[j]));
+        dM += val(dthick[j]) * dj[j];
+      }
+    };
     auto eval = [&](R x) {
       R thk, dthk;
+      if constexpr (COOP && K > 0) {
+        if (together) {
+          R th, dt, tj[NL], dj[NL];
+          theta_slope(c_al, c_n, c_m, c_te, c_tr, x, th, dt);
+          xchg[2 * c_q] = th;  // (lanes with the same c_q store the same value to the same address)
+          xchg[2 * c_q + 1] = dt;
+          lds_exchange_point();
+          thk = xchg[2 * K];
+          dthk = xchg[2 * K + 1];
+#pragma unroll
+          for (int j = 0; j < K; j++) { tj[j] = xchg[2 * j]; dj[j] = xchg[2 * j + 1]; }
+          lds_exchange_point();
+          sums(thk, dthk, tj, dj);
+          last_x = x;
+          last_th = thk;
+          return;
+        }
+      }
       theta_slope(val(lk.alpha), val(lk.n), val(lk.m), val(lk.te), val(lk.tr), x, thk, dthk);
       M = val(dthick_k) * (thk - val(dth_k));
       dM = val(dthick_k) * dthk;
 #pragma unroll
       for (int j = 0; j < K; j++) {
-        R tj, dj;
-        theta_slope(val(P.alpha[j]), val(P.n[j]), val(P.m[j]), val(P.te[j]), val(P.tr[j]), x, tj, dj);
-        M += val(dthick[j]) * (tj - val(dth[j]));
-        dM += val(dthick[j]) * dj;
+        R t1, d1;
+        theta_slope(val(P.alpha[j]), val(P.n[j]), val(P.m[j]), val(P.te[j]), val(P.tr[j]), x, t1, d1);
+        M += val(dthick[j]) * (t1 - val(dth[j]));
+        dM += val(dthick[j]) * d1;
       }
     };
     R lo = R(0.0), hi = R(-1.0);  // bracket f(lo) > 0 > f(hi); hi < 0: not found yet
     bool lo_ok = false;
-    eval(psi);
+    if (fe.have) {  // (cooperating lanes: evaluated with the sweep's own thetas)
+      sums(fe.thk, fe.dthk, fe.th, fe.dth);
+      last_x = psi;
+      last_th = fe.thk;
+    } else {
+      eval(psi);
+    }
     f = M - prior;
     for (int it = 0; it < 64; it++) {
       if (ab(f) <= Tol<R>::mass) break;
@@ -1214,6 +1391,11 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
       if (it == 63) status |= LGAR_ST_ITERCAP;
     }
     const S psi_final = psi0 + (psi - val(psi0));
+    if constexpr (COOP && K > 0) {
+      // theta(psi_final) was part of the last mass evaluation whenever psi0 + (psi - psi0) is psi bit for bit (the difference
+      // is exact for psi within a factor of two of psi0): theta_slope's theta is theta_from_h's, operation by operation
+      if (val(psi_final) == last_x) return S(last_th);
+    }
     return theta_from_h<S, POL>(lk, psi_final);
   }
 
@@ -1221,7 +1403,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
   // dth/dthick hold the entries of the layers above (j < K), dth_k/dthick_k the front's own.
   template <int K>
   __device__ __forceinline__ S theta_mass_balance(const LayerK<S> &lk, S psi, S new_mass, S prior_mass, const S (&dth)[NL],
-                                  const S (&dthick)[NL], S dth_k, S dthick_k) {
+                                  const S (&dthick)[NL], S dth_k, S dthick_k, const FirstEval &fe = FirstEval()) {
     R delta_mass = ab(val(new_mass) - val(prior_mass));
     bool switched = false;
     R factor = R(1.0);
@@ -1231,7 +1413,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
     int count_no_change = 0;
     if (delta_mass <= Tol<R>::mass) return theta_from_h<S, POL>(lk, psi);
     LGAR_MEASURE_POINT(NOSEARCH, lk, psi, new_mass)
-    if constexpr (MODE != 0) return theta_mass_balance_newton<K>(lk, psi, new_mass, prior_mass, dth, dthick, dth_k, dthick_k);
+    if constexpr (MODE != 0) return theta_mass_balance_newton<K>(lk, psi, new_mass, prior_mass, dth, dthick, dth_k, dthick_k, fe);
     long long it = 0;
     while (delta_mass > Tol<R>::mass) {
       if (++it > G->iter_cap) { status |= LGAR_ST_ITERCAP; break; }
@@ -1336,10 +1518,52 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
     S on_z, on_th, on_ps;  // pre-sweep values of front i+1
   };
 
+  // Cooperating lanes: the 6 K thetas an in-layer front of layer K needs before its search (theta of every layer above at
+  // the front's and the next front's psi, before and after the move -- compute_wetting_front_mass, Layer.py:561-644) are three
+  // distinct evaluations per layer above (the front's own psi has not changed yet: "old" and "new" are one value), and the
+  // search's first mass evaluation needs K + 1 more at the front's psi.  Lane r of the group evaluates item r (items
+  // 3 j + {0: psi, 1: psi of the next front before the sweep, 2: after}; item 3 K: the front's own layer at psi), in rounds of
+  // `share_lanes` items; the serial chain of 2 (7 K + 1) pows becomes one of 2 per round.  theta_slope's theta is
+  // theta_from_h's operation by operation.
+  template <int K>
+  __device__ __forceinline__ void coop_sweep_thetas(const LayerK<S> &lk, R psi, R psi_below_old, R psi_below, FirstEval &fe,
+                                                    R (&th_below_old)[NL], R (&th_below)[NL]) {
+    constexpr int CNT = 3 * K + 1;
+    for (int first = 0; first < CNT; first += share_lanes) {
+      const int q = first + coop_rank;
+      const bool mine = (coop_rank < share_lanes) && (q < CNT);
+      R al = val(lk.alpha), n = val(lk.n), m = val(lk.m), te = val(lk.te), tr = val(lk.tr), x = psi;
+#pragma unroll
+      for (int j = 0; j < K; j++) {
+        const bool lj = (q >= 3 * j) && (q < 3 * j + 3);
+        al = choose(lj, val(P.alpha[j]), al); n = choose(lj, val(P.n[j]), n); m = choose(lj, val(P.m[j]), m);
+        te = choose(lj, val(P.te[j]), te); tr = choose(lj, val(P.tr[j]), tr);
+        x = choose(q == 3 * j + 1, psi_below_old, x);
+        x = choose(q == 3 * j + 2, psi_below, x);
+      }
+      R th, dt;
+      theta_slope(al, n, m, te, tr, x, th, dt);
+      if (mine) { xchg[2 * q] = th; xchg[2 * q + 1] = dt; }
+    }
+    lds_exchange_point();
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+      fe.th[j] = xchg[2 * (3 * j)];
+      fe.dth[j] = xchg[2 * (3 * j) + 1];
+      th_below_old[j] = xchg[2 * (3 * j + 1)];
+      th_below[j] = xchg[2 * (3 * j + 2)];
+    }
+    fe.thk = xchg[2 * (3 * K)];
+    fe.dthk = xchg[2 * (3 * K) + 1];
+    fe.have = true;
+    lds_exchange_point();
+  }
+
   template <int K> __device__ __forceinline__ void sweep_layer(SweepCarry &c) {
     const LayerK<S> lk = pick_static(P, K);
     const int last = c.i;  // deepest front of this layer's list (if the lane has fronts tagged K)
     while (c.i >= 0 && F.layer(c.i) == K) {
+      LGAR_MEASURE_POINT(CLK, 19)
       const int i = c.i;
       const S oc_z = F.Z(i), oc_th = F.TH(i), oc_ps = F.PS(i);  // pre-sweep values of front i
       bool need_psi = false;
@@ -1352,6 +1576,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
           if constexpr (MODE != 0 && sizeof(R) == 8) {
             if (__builtin_expect(val(ap) < R(1e-6), 0)) c.near_sat |= 1u << i;
           }
+          LGAR_MEASURE_POINT(CLK, 20)
         } else if constexpr (K == 0) {
           S prior_mass = oc_z * (oc_th - c.on_th);
           if (i == c.fdd || feq(c.fdd, i)) prior_mass = prior_mass + (c.infiltration - (R(0.0) + c.aet));
@@ -1373,6 +1598,22 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
           S psi = F.PS(i), psi_below = F.PS(i + 1);
           S prior_mass = (oc_z - prev_thick) * (oc_th - c.on_th);
           S new_mass = (z - prev_thick) * (F.TH(i) - F.TH(i + 1));
+          FirstEval fe;
+          if constexpr (COOP) {
+            if (share_lanes >= 4) {  // cooperating lanes: the thetas below, evaluated by the group together
+              R tbo[NL], tb[NL];
+              coop_sweep_thetas<K>(lk, psi, psi_below_old, psi_below, fe, tbo, tb);
+#pragma unroll
+              for (int j = 0; j < K; j++) {
+                S lt = P.cum[j] - R(0.0);
+                prior_mass = prior_mass + (lt * (fe.th[j] - tbo[j]));  // (psi_old is psi: the front's own psi has not moved yet)
+                new_mass = new_mass + (lt * (fe.th[j] - tb[j]));
+                dth[j] = tb[j];
+                dthick[j] = lt;
+              }
+            }
+          }
+          if (!fe.have) {
 #pragma unroll
           for (int j = 0; j < K; j++) {
             const LayerK<S> lj = pick_static(P, j);
@@ -1386,13 +1627,16 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
             dth[j] = theta_below;
             dthick[j] = lt;
           }
+          }
           const S t_dth_k = F.TH(i + 1);
           const S t_dthick_k = z - prev_thick;
           if (i == c.fdd || feq(c.fdd, i)) prior_mass = prior_mass + c.infiltration - (R(0.0) + c.aet);
+          LGAR_MEASURE_POINT(CLK, 22)
           LGAR_MEASURE_POINT(DUP_SEARCH, K, lk, psi, new_mass, prior_mass, dth, dthick, t_dth_k, t_dthick_k)
-          S theta_new = theta_mass_balance<K>(lk, psi, new_mass, prior_mass, dth, dthick, t_dth_k, t_dthick_k);
+          S theta_new = theta_mass_balance<K>(lk, psi, new_mass, prior_mass, dth, dthick, t_dth_k, t_dthick_k, fe);
           F.TH(i) = mn(theta_new, lk.te);
           need_psi = true;
+          LGAR_MEASURE_POINT(CLK, 23)
         }
       } else if constexpr (K == NL - 1) {
         if (c.nf0 == NL) {
@@ -1423,6 +1667,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
         }
       }
       if (need_psi) F.PS(i) = h_from_se<S, POL>(lk, se_from_theta(lk, F.TH(i)));
+      LGAR_MEASURE_POINT(CLK, 24)
       c.on_z = oc_z; c.on_th = oc_th; c.on_ps = oc_ps;
       c.i = i - 1;
     }
@@ -1617,6 +1862,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
   // crashing in the layer-boundary step first; here that case sets LGAR_ST_BOTTOM and the flux is 0.
   __device__ __forceinline__ S move_wetting_front(S infiltration, S &aet, S old_mass, int fdd) {
     move_sweep(infiltration, aet, old_mass, fdd);
+    LGAR_MEASURE_POINT(CLK, 3)
     S bottom_flux = S(R(0.0));
     // (a per-lane decision: a column's results must not depend on which other columns share its wave)
     LGAR_MEASURE_POINT(DUP_EVENT)
@@ -1651,6 +1897,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
     // from (a layer's deepest front), so the pass only adds a theta -> psi -> theta round trip: MODE 0 keeps it, MODE 1
     // runs it only after an event.
     if constexpr (MODE == 0) update_psi();
+    LGAR_MEASURE_POINT(CLK, 4)
     LGAR_MEASURE_POINT(DUP_PSI)
     return bottom_flux;
   }
@@ -1673,6 +1920,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
         else F.DZ(i) = S(R(0.0));
       }
       if (any_lane(found) == 0ull) break;
+      LGAR_MEASURE_POINT(CLK, 10)
       if (found) {
         const int k = F.layer(i);
         const LayerK<S> lk = pick(P, k);
@@ -1685,6 +1933,36 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
             double kr_end;
             g = capillary_drive_fronts(lk, theta_1, theta_2, F.PS(i + 1), F.PS(i), kr_end);
             ki = lk.ksat * kr_end;
+            if (i == 0 && new_front_frozen) ki = ki * G->frozen;
+            fronts_done = true;
+          }
+        }
+        CoopRiders riders;  // (cooperating lanes only)
+        if constexpr (COOP) {
+          // cooperating lanes: the front's own K(theta) and the K of the layers above at its psi (two pows each, after the
+          // two of theta(psi)) ride along with the four evaluations that open the trapezoid -- see CoopRiders
+          if (!G->closed_form && share_lanes >= 5 + k) {
+            const int e = coop_rank - 5;  // my layer above (lanes 5 .. 5 + k - 1)
+            LayerK<S> le = lk;
+            S th_e = F.TH(i);
+            if (k > 0) {
+#pragma unroll
+              for (int j = 0; j < NL - 1; j++) {
+                const bool mine = (e == j) && (j < k);
+                le.alpha = choose(mine, P.alpha[j], le.alpha); le.n = choose(mine, P.n[j], le.n); le.m = choose(mine, P.m[j], le.m);
+                le.inv_m = choose(mine, P.inv_m[j], le.inv_m); le.ksat = choose(mine, P.ksat[j], le.ksat);
+                le.te = choose(mine, P.te[j], le.te); le.tr = choose(mine, P.tr[j], le.tr);
+              }
+              const S tl = theta_from_h<S, POL>(le, F.PS(i));
+              th_e = choose(e >= 0 && e < k, tl, th_e);
+            }
+            riders.n = 1 + k;
+            riders.l = le;
+            riders.se = se_from_theta(le, th_e);
+#pragma unroll
+            for (int q = 0; q < LGAR_LMAX; q++) riders.k[q] = R(1.0);
+            g = capillary_drive(lk, theta_1, theta_2, 1, &riders);
+            ki = riders.k[0];
             if (i == 0 && new_front_frozen) ki = ki * G->frozen;
             fronts_done = true;
           }
@@ -1703,14 +1981,22 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
           for (int j = 0; j < NL - 1; j++)
             if (j < k) {
               const LayerK<S> lj = pick_static(P, j);
-              S tl = theta_from_h<S, POL>(lj, F.PS(i));
-              S kl = k_from_se<S, POL>(lj, se_from_theta(lj, tl));
+              S kl;
+              bool rode = false;
+              if constexpr (COOP) {
+                if (riders.n > 0) { kl = riders.k[1 + j]; rode = true; }
+              }
+              if (!rode) {
+                S tl = theta_from_h<S, POL>(lj, F.PS(i));
+                kl = k_from_se<S, POL>(lj, se_from_theta(lj, tl));
+              }
               S pt = (j != 0) ? P.cum[(j > 0) ? j - 1 : 0] : S(R(0.0));
               den = den + dv<POL>(P.cum[j] - pt, kl);
             }
           dzdt = dv<POL>(S(R(1.0)), delta_theta) * (dv<POL>(F.Z(i), den) + dv<POL>(lk.ksat * (g + h_p), F.Z(i)));
         }
         F.DZ(i) = dzdt;
+        LGAR_MEASURE_POINT(CLK, 17)
       }
     }
   }
@@ -1877,6 +2163,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
       S ponded_water_sub = S(R(0.0)), runoff_sub = S(R(0.0)), infiltration_sub = S(R(0.0)), AET_sub = S(R(0.0));
       // create_surficial_front predicate, models/dpLGAR.py:310-323
       const bool create = (val(previous_precip) == R(0.0)) && (val(precip_sub) > R(0.0)) && (val(ponded_water) == R(0.0));
+      LGAR_MEASURE_POINT(CLK, 0)
       LGAR_MEASURE_POINT(DUP_FDD)
       const int fdd = free_drainage_front();
       const bool saturated = val(F.TH(0)) >= val(P.te[0]);  // Layer.is_saturated, Layer.py:785-793
@@ -1894,12 +2181,14 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
       // infiltrate (insert_water) and then move.  update_ponded_depth touches no front state, so doing it
       // after the move is equivalent.
       const bool inserting = !create && val(ponded_depth_sub) > R(0.0);
+      LGAR_MEASURE_POINT(CLK, 1)
       if (inserting) {
         LGAR_ABLATABLE(INSERT, insert_water(fdd, precip_sub, ponded_depth_sub, infiltration_sub, runoff_sub);)
         a_infil = a_infil + infiltration_sub;
         a_runoff = a_runoff + runoff_sub;
         ponded_water_sub = ponded_depth_sub;
       }
+      LGAR_MEASURE_POINT(CLK, 2)
       if (!create || !saturated) {
         S perc_sub = S(R(0.0));
         LGAR_ABLATABLE(MOVE, perc_sub = move_wetting_front(create ? S(R(0.0)) : infiltration_sub, AET_sub, ending_volume_sub, fdd);)
@@ -1923,10 +2212,13 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
           a_runoff = a_runoff + runoff_sub;
         }
       }
+      LGAR_MEASURE_POINT(CLK, 5)
       LGAR_ABLATABLE(DZDT, calc_dzdt(ponded_depth_sub);)
+      LGAR_MEASURE_POINT(CLK, 6)
       LGAR_MEASURE_POINT(DUP_DZDT, ponded_depth_sub)
       LGAR_MEASURE_POINT(DUP_MB, ending_volume_sub)
       ending_volume_sub = mass_balance();
+      LGAR_MEASURE_POINT(CLK, 7)
       previous_precip = precip_sub;
       ending_volume = ending_volume_sub;
       a_aet = a_aet + AET_sub;
@@ -1954,6 +2246,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
       } else {
         if (is_nan(val(ending_volume_sub))) status |= LGAR_ST_NAN;
       }
+      LGAR_MEASURE_POINT(CLK, 8)
     }
   }
 };

@@ -57,10 +57,12 @@ template <int SR> __device__ __forceinline__ constexpr int sum_row(int j) {
 template <typename S, int FMAX, int SUMROWS = LdsSums<S, FMAX>::rows, int STRIDE = WAVE> struct WaveLDS {
   S f[4][FMAX][STRIDE];
   unsigned char fl[FMAX][STRIDE];
-  S sums[SUMROWS][WAVE];
+  S sums[SUMROWS][STRIDE];
 };
-// the wave's LDS block of a forward kernel: one front table per lane, or (MODE 4) per group of cooperating lanes
-template <typename R, int FMAX, int MODE> using ForwardLDS = WaveLDS<R, FMAX, LdsSums<R, FMAX>::rows, (MODE == 4) ? LGAR_COOP_GROUPS : WAVE>;
+// the wave's LDS block of a forward kernel: one front table (and one row of sums) per lane, or (MODE 4) per group of
+// cooperating lanes
+template <typename R, int FMAX, int MODE>
+using ForwardLDS = WaveLDS<R, FMAX, LdsSums<R, FMAX>::rows, coop_mode(MODE) ? LGAR_COOP_GROUPS : WAVE>;
 
 #ifndef LGAR_DEVSIM
 __device__ __forceinline__ double wave_sum(double v) {
@@ -184,7 +186,7 @@ __device__ __forceinline__ void forward_lane(const LGAR_KARG KArgs<R> *ap, size_
   load_params<R, NL>(a, c, P);
   // front-table slot: my own, or (MODE 4) my group's -- the lanes of a group hold the same column
   constexpr int STRIDE = Column<R, NL, FMAX, MODE>::STRIDE;
-  const int slot = (MODE == 4) ? group : lane;
+  const int slot = coop_mode(MODE) ? group : lane;  // (also my column of the LDS sums)
   Column<R, NL, FMAX, MODE> col(P, &ap->G, make_view<R, FMAX, STRIDE>(&lds.f[0][0][0], &lds.fl[0][0], slot));
   // state HBM -> LDS / registers
   const int nf_stored = a.nf[c];
@@ -220,7 +222,7 @@ __device__ __forceinline__ void forward_lane(const LGAR_KARG KArgs<R> *ap, size_
 #pragma unroll
   for (int j = 0; j < 8; j++) {
     tot[j] = R(0);
-    if (j < SR) lds.sums[j][lane] = R(0);
+    if (j < SR) lds.sums[j][slot] = R(0);
   }
   double wgt = 0.0;
   if (basin_on && leader) wgt = a.weights ? (double)a.weights[c] : 1.0;
@@ -252,13 +254,34 @@ __device__ __forceinline__ void forward_lane(const LGAR_KARG KArgs<R> *ap, size_
   const int T = a.T;
   const size_t Nf = (size_t)a.Nf;
   const size_t cf = (Nf == N) ? c : (c / (size_t)a.Fg) % Nf;  // this column's forcing column
+  // (MODE 4, one wave per SIMD and registers to spare: the NEXT step's forcing is loaded a step ahead -- a lone wave has nothing
+  // else to cover the ~1 us of that load with)
+  R precip_ahead = R(0), pet_ahead = R(0);
+  if constexpr (coop_mode(MODE)) {
+    if (T > 0) {
+      precip_ahead = a.precip[cf];
+      pet_ahead = a.pet[cf];
+    }
+#ifndef LGAR_DEVSIM
+    asm volatile("" : "+v"(precip_ahead), "+v"(pet_ahead));  // (in their registers before the loop: see the loop's own note)
+#endif
+  }
   for (int t = 0; t < T; t++) {
     ap = launder(ap);
     const LGAR_KARG KArgs<R> &a = *ap;  // (shadows the outer reference on purpose)
     col.G = &ap->G;
     const size_t o = (size_t)t * N + c;
-    const R precip = a.precip[(size_t)t * Nf + cf];
-    const R pet = a.pet[(size_t)t * Nf + cf];
+    R precip, pet;
+    if constexpr (coop_mode(MODE)) {
+      precip = precip_ahead;
+      pet = pet_ahead;
+      const size_t tn = (size_t)((t + 1 < T) ? t + 1 : t);
+      precip_ahead = a.precip[tn * Nf + cf];
+      pet_ahead = a.pet[tn * Nf + cf];
+    } else {
+      precip = a.precip[(size_t)t * Nf + cf];
+      pet = a.pet[(size_t)t * Nf + cf];
+    }
     bool active = (t >= t_begin) && (t < t_stop);
     if (active && !a.chain_last && col.nf + a.G.nsub > FMAX) {
       // this step could outgrow the kernel's front capacity: hand the column over, state as of the end of step t-1
@@ -267,6 +290,13 @@ __device__ __forceinline__ void forward_lane(const LGAR_KARG KArgs<R> *ap, size_
     }
     if (any_lane(active) == 0ull) continue;
     if (active) col.forward(precip, pet);
+#ifndef LGAR_DEVSIM
+    if constexpr (coop_mode(MODE)) {
+      // the forcing loaded a step ahead is taken into its registers HERE, before this step's stores are issued: loads and
+      // stores share one counter, and a wait for the load placed after the stores would wait for the stores as well
+      asm volatile("" : "+v"(precip_ahead), "+v"(pet_ahead));
+    }
+#endif
     const R acc[LGAR_NACC] = {col.a_precip, col.a_pet, col.a_aet, col.a_infil, col.a_runoff,
                               col.a_perc, col.a_giuh, col.a_disch, col.ponded_water, col.ending_volume};
     if (active && leader) {
@@ -289,7 +319,7 @@ __device__ __forceinline__ void forward_lane(const LGAR_KARG KArgs<R> *ap, size_
       for (int j = 0; j < 7; j++) {  // MassBalance.change_mass, MassBalance.py:31-44
         if (j == 5 && a.G.bottom_mode == 0) continue;  // percolation is identically zero in the reference's mode
         const int row = sum_row<SR>(j);
-        if (row >= 0) lds.sums[row][lane] = lds.sums[row][lane] + acc[j];
+        if (row >= 0) lds.sums[row][slot] = lds.sums[row][slot] + acc[j];
         else tot[j] = tot[j] + acc[j];
       }  // (discharge [7] is the same sum as giuh_runoff [6]: both gain the same routed runoff, models/dpLGAR.py:293-297)
       col.drain();
@@ -327,7 +357,7 @@ __device__ __forceinline__ void forward_lane(const LGAR_KARG KArgs<R> *ap, size_
   store_state<R, NL, FMAX, MODE>(z, c, col, nf_before, word);
 #pragma unroll
   for (int j = 0; j < 7; j++)
-    if (sum_row<SR>(j) >= 0) tot[j] = lds.sums[sum_row<SR>(j)][lane];
+    if (sum_row<SR>(j) >= 0) tot[j] = lds.sums[sum_row<SR>(j)][slot];
   tot[7] = tot[6];
 #pragma unroll
   for (int j = 0; j < 8; j++) z.totals[j * N + c] = z.totals[j * N + c] + tot[j];  // MassBalance's run totals

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(WAVE) void lgar_init_kernel(KArgs<R> a) {
 // per group of lanes, MODE 4 kernels only (double precision).  With the front table kept once per group as well, a 32-front
 // wave of such a kernel takes 37 KB: four waves per CU, one per SIMD -- all a cooperating job may have.
 template <typename R, int MODE> struct CoopLDS {
-  static constexpr bool on = (sizeof(R) == 8) && (MODE == 4);
+  static constexpr bool on = (sizeof(R) == 8) && coop_mode(MODE);
   R tab[on ? LGAR_COOP_GROUPS : 1][on ? LGAR_COOP_TAB_ROW : 1];
 };
 
@@ -244,6 +244,15 @@ extern "C" int lgar_debug_counters(unsigned long long *out, int reset) {
   unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(lgar_dbg_counters), sizeof(z)) != hipSuccess) return -1;
   if (reset && hipMemcpyToSymbol(HIP_SYMBOL(lgar_dbg_counters), z, sizeof(z)) != hipSuccess) return -1;
+  return 0;
+}
+#endif
+
+#if defined(LGAR_MEASURE) && defined(LGAR_CLOCKS)
+extern "C" int lgar_debug_clocks(unsigned long long *out, int reset) {
+  unsigned long long z[64] = {0};
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(lgar_dbg_clk), sizeof(z)) != hipSuccess) return -1;
+  if (reset && hipMemcpyToSymbol(HIP_SYMBOL(lgar_dbg_clk), z, sizeof(z)) != hipSuccess) return -1;
   return 0;
 }
 #endif

@@ -143,3 +143,24 @@ static __device__ unsigned long long lgar_dbg_counters[8];
     atomicAdd(&lgar_dbg_counters[5], (unsigned long long)__builtin_popcountll(any_lane(true)));    \
   }
 #endif
+
+// ---- cycle attribution (-DLGAR_CLOCKS): LGAR_MEASURE_POINT(CLK, id) adds the shader-clock cycles since the previous point
+// of the same wave to slot id -- the first wave of the grid only, so a one-wave job (a single column with cooperating lanes)
+// reads as a profile of its step; read back with lgar_debug_clocks (lgar_kernels_nl.hip, measurement builds only)
+#ifdef LGAR_CLOCKS
+static __device__ unsigned long long lgar_dbg_clk[64];
+static __shared__ unsigned long long lgar_dbg_clk_last;
+#define LGAR_POINT_CLK(id)                                                                         \
+  if (blockIdx.x == 0) {                                                                           \
+    const unsigned long long now_ = __builtin_readcyclecounter();                                  \
+    if (first_active_lane()) {                                                                     \
+      if (now_ - lgar_dbg_clk_last < (1ull << 36)) { /* (not the wave's first point: no previous one) */ \
+        atomicAdd(&lgar_dbg_clk[id], now_ - lgar_dbg_clk_last);                                    \
+        atomicAdd(&lgar_dbg_clk[32 + id], 1ull);                                                   \
+      }                                                                                            \
+      lgar_dbg_clk_last = now_;                                                                    \
+    }                                                                                              \
+  }
+#else
+#define LGAR_POINT_CLK(id)
+#endif

@@ -569,6 +569,34 @@ def test_cooperating_lanes_reproduce_one_lane_per_column(name, lanes):
     assert torch.equal(ea.totals, eb.totals)
 
 
+@pytest.mark.parametrize("nint", [7, 24, 50, 121, 128])
+@pytest.mark.parametrize("lanes", [4, 9, 64])
+def test_cooperating_lanes_other_interval_counts(nint, lanes):
+    """The cooperative trapezoid at interval counts other than the bundled 120: heads in batches of 16 (+ a tail), nodes and
+    terms in rounds of two or four per lane (ragged last rounds), the sum in batches of 16 + 8 + a tail -- bit for bit one lane
+    per column (three-layer and six-layer soil: riders and search evaluations of every layer count)."""
+    import lgar_py_amd as lg
+    for name in ("synth1_phil", "six_layer_synth1"):
+        g = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+        g["nint"] = np.int64(nint)
+
+        class G(dict):
+            files = list(g)
+        gg = G(g)
+        res = {}
+        for k in (1, lanes):
+            eng = _engine(gg, 3, torch.float64, forward_lanes=k)
+            pr, pe = _forcing(gg, 3)
+            out = eng.forward(pr, pe, series=lg.ACC_NAMES, check=False)
+            res[k] = (out, eng)
+        a, ea = res[1]
+        b, eb = res[lanes]
+        for nm in lg.ACC_NAMES:
+            assert torch.equal(a[nm], b[nm]), (name, nm)
+        for t in ("depth", "theta", "psi", "k", "dzdt", "flags", "n_fronts", "status", "totals"):
+            assert torch.equal(getattr(ea, t), getattr(eb, t)), (name, t)
+
+
 def test_cooperating_lanes_on_distinct_columns_and_the_default_choice():
     """200 different columns: the library's own choice (64 lanes for this size) and a forced 7 reproduce one lane per column."""
     import lgar_py_amd as lg

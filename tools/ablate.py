@@ -25,6 +25,8 @@ VARIANTS = {
     "nogeff_nodzdt": ["-DLGAR_ABL_NOGEFF", "-DLGAR_ABL_NODZDT"],
     "nogeff_nomove": ["-DLGAR_ABL_NOGEFF", "-DLGAR_ABL_NOMOVE"],
     "nogeff_noinsert": ["-DLGAR_ABL_NOGEFF", "-DLGAR_ABL_NOINSERT"],
+    "nogeff_nosearch": ["-DLGAR_ABL_NOGEFF", "-DLGAR_ABL_NOSEARCH"],
+    "clocks": ["-DLGAR_CLOCKS"],  # cycle attribution of a one-wave job: tools/smalljob_clocks.py
     "skeleton": ["-DLGAR_ABL_NOGEFF", "-DLGAR_ABL_NODZDT", "-DLGAR_ABL_NOMOVE", "-DLGAR_ABL_NOINSERT"],
     "contract": ["-ffp-contract=fast"],
     "count_lanes": ["-DLGAR_COUNT_LANES"],  # geff_calls then counts LANE-level evaluations (base: wave-level)
