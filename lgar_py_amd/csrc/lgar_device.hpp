@@ -60,6 +60,9 @@ __device__ __forceinline__ void lds_exchange_point() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   __builtin_amdgcn_wave_barrier();
 }
+// a value loaded from memory a step ahead is taken into its register HERE (the wait for the load is placed at this point):
+// loads and stores share one counter, and a wait placed after later stores would wait for those as well
+template <typename T> __device__ __forceinline__ void settle_load(T &x) { asm volatile("" : "+v"(x)); }
 #else  // tests/devsim: the same device code compiled for the host, one lane at a time (test infrastructure only)
 __device__ __forceinline__ float lg2(float x) { return log2f(x); }
 __device__ __forceinline__ float ex2(float x) { return exp2f(x); }
@@ -68,6 +71,7 @@ __device__ __forceinline__ float clamp01(float x) { return fminf(fmaxf(x, 0.0f),
 __device__ __forceinline__ unsigned long long any_lane(bool p) { return p ? 1ull : 0ull; }
 __device__ __forceinline__ bool first_active_lane() { return true; }
 __device__ __forceinline__ void lds_exchange_point() {}
+template <typename T> __device__ __forceinline__ void settle_load(T &) {}
 #endif
 __device__ __forceinline__ float pw(float x, float y) { return ex2(y * lg2(x)); }
 // EX = true (verification mode, double precision only): the correctly rounded library pow, as the reference's torch.pow;
@@ -469,6 +473,14 @@ __device__ __forceinline__ void geff_nodes_cooperative(const LayerK<double> &l, 
   LGAR_MEASURE_POINT(CLK, 16)
 }
 #endif
+// (cooperating lanes, calc_dzdt: conductivities that ride along with the evaluations that open a trapezoid -- see
+// geff_ends_cooperative)
+struct CoopRiders {
+  int n = 0;           // riders of this call (the group needs 4 + n lanes)
+  LayerK<double> l;    // MY rider's layer and Se (lanes 4 .. 4 + n - 1; anything elsewhere)
+  double se = 1.0;
+  double k[LGAR_LMAX]; // out: K of rider e
+};
 #ifndef LGAR_DEVSIM
 // The four two-pow evaluations that open a trapezoid -- h(Se_i), h(Se_f) (calc_h_from_se), K(Se_i), K(1) (calc_k_from_se) -- for
 // COOPERATING lanes: lane r of a group evaluates number r mod 4 and the group exchanges the results.  Both functions are
@@ -479,12 +491,6 @@ __device__ __forceinline__ void geff_nodes_cooperative(const LayerK<double> &l, 
 // K of every layer above at the front's psi (calc_bottom_sum, Layer.py:1557-1582) -- are the same "pow, offset, nudge, pow,
 // finish": lane 4 + e of the group takes rider e, with that rider's layer (xl) and Se (xse) as ITS operands, and every lane
 // reads the n_riders results back into xk before the table is reused for the trapezoid's heads.
-struct CoopRiders {
-  int n = 0;           // riders of this call (the group needs 4 + n lanes)
-  LayerK<double> l;    // MY rider's layer and Se (lanes 4 .. 4 + n - 1; anything elsewhere)
-  double se = 1.0;
-  double k[LGAR_LMAX]; // out: K of rider e
-};
 __device__ __forceinline__ void geff_ends_cooperative(const LayerK<double> &l, double se_i, double se_f, double &h_i, double &h_f,
                                                       double &k_i, double &k_sat1, double *xchg, int r, CoopRiders *rd = nullptr) {
   const bool rider = (rd != nullptr) && (r >= 4) && (r - 4 < rd->n);
@@ -516,8 +522,6 @@ __device__ __forceinline__ void geff_ends_cooperative(const LayerK<double> &l, d
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   __builtin_amdgcn_wave_barrier();
 }
-#else
-struct CoopRiders { int n = 0; LayerK<double> l; double se = 1.0; double k[LGAR_LMAX]; };
 #endif
 template <typename S>
 __device__ __forceinline__ S geff_fused(const LayerK<S> &l, S theta1, S theta2, int nint, real_t<S> *xchg = nullptr, int coop = 0,
@@ -1230,9 +1234,54 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
       if (F.layer(i) == k) { if (len == 0) lo = i; len++; }
   }
 
+  // Cooperating lanes (one wave alone on its SIMD): every dependent LDS read is ~130 cycles nothing else covers, and the column
+  // mass reads the front table row by row.  A table of at most SCAN fronts (the usual case) is fetched in ONE round trip
+  // instead, and the sum runs on registers with the row index a compile-time constant: the same terms in the same order, so the
+  // same result bit for bit.  (The event scan and the free-drainage search gained nothing from the same treatment: what they
+  // save in waits they spend on selects.)
+  static constexpr bool COOP = coop_mode(MODE) && (sizeof(S) == 8) && (sizeof(R) == 8);
+  static constexpr int SCAN = 8;
+  struct Rows {
+    R z[SCAN], th[SCAN];
+    int fl[SCAN];
+  };
+  __device__ __forceinline__ void fetch_rows(Rows &r) const {
+#pragma unroll
+    for (int q = 0; q < SCAN; q++) {
+      r.z[q] = val(F.Z(q));
+      r.th[q] = val(F.TH(q));
+      r.fl[q] = F.flag(q);
+    }
+  }
+
   // Layer.mass_balance, layers/Layer.py:795-824 (layer sums combined s0 + (s1 + (s2 ...)))
   __device__ __forceinline__ S mass_balance() const {
     S ls[NL];
+    if constexpr (COOP) {
+      if (nf <= SCAN) {  // cooperating lanes: the table's first rows in one fetch (see Rows)
+        Rows r;
+        fetch_rows(r);
+#pragma unroll
+        for (int j = 0; j < NL; j++) ls[j] = S(R(0.0));
+#pragma unroll
+        for (int q = 0; q < SCAN; q++) {
+          const bool on = q < nf;
+          const int lay = r.fl[q] & 0x7f;
+          const bool next_same = (q + 1 < nf) && ((r.fl[(q + 1 < SCAN) ? q + 1 : q] & 0x7f) == lay);
+          const R dth = next_same ? r.th[q] - r.th[(q + 1 < SCAN) ? q + 1 : q] : r.th[q];
+          R base = R(0.0);
+#pragma unroll
+          for (int j = 1; j < NL; j++) base = choose(lay == j, val(P.cum[j]) - val(P.thick[j]), base);
+          const R term = (r.z[q] - base) * dth;
+#pragma unroll
+          for (int j = 0; j < NL; j++) ls[j] = choose(on && lay == j, ls[j] + term, ls[j]);  // (a layer's fronts are adjacent:
+        }                                                                                  //  each sum grows in table order)
+        S tot = ls[NL - 1];
+#pragma unroll
+        for (int j = NL - 2; j >= 0; j--) tot = ls[j] + tot;
+        return tot;
+      }
+    }
     int i = 0;
 #pragma unroll
     for (int j = 0; j < NL; j++) {
@@ -1283,7 +1332,6 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
   // theta(psi) -- two pows each -- so lane r of the group evaluates layer min(r, K) with that layer's parameters as its
   // operands (ONE instruction stream) and the group exchanges the results through its LDS table; the sums are formed from
   // them in the serial order.  Every value goes through exactly the operations of the serial evaluation: bit-identical.
-  static constexpr bool COOP = coop_mode(MODE) && (sizeof(S) == 8) && (sizeof(R) == 8);
   // ... and what the group evaluated together BEFORE a search (coop_sweep_thetas): theta and d theta / d psi of the layers
   // above and of the front's own layer at the front's psi -- the search's first mass evaluation
   struct FirstEval {
@@ -1615,18 +1663,18 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
           }
           if (!fe.have) {
 #pragma unroll
-          for (int j = 0; j < K; j++) {
-            const LayerK<S> lj = pick_static(P, j);
-            S theta_old = theta_from_h<S, POL>(lj, psi_old);
-            S theta_below_old = theta_from_h<S, POL>(lj, psi_below_old);
-            S lt = P.cum[j] - R(0.0);  // quirk: cumulative thickness (Layer.py:603-604)
-            prior_mass = prior_mass + (lt * (theta_old - theta_below_old));
-            S theta = theta_from_h<S, POL>(lj, psi);
-            S theta_below = theta_from_h<S, POL>(lj, psi_below);
-            new_mass = new_mass + (lt * (theta - theta_below));
-            dth[j] = theta_below;
-            dthick[j] = lt;
-          }
+            for (int j = 0; j < K; j++) {
+              const LayerK<S> lj = pick_static(P, j);
+              S theta_old = theta_from_h<S, POL>(lj, psi_old);
+              S theta_below_old = theta_from_h<S, POL>(lj, psi_below_old);
+              S lt = P.cum[j] - R(0.0);  // quirk: cumulative thickness (Layer.py:603-604)
+              prior_mass = prior_mass + (lt * (theta_old - theta_below_old));
+              S theta = theta_from_h<S, POL>(lj, psi);
+              S theta_below = theta_from_h<S, POL>(lj, psi_below);
+              new_mass = new_mass + (lt * (theta - theta_below));
+              dth[j] = theta_below;
+              dthick[j] = lt;
+            }
           }
           const S t_dth_k = F.TH(i + 1);
           const S t_dthick_k = z - prev_thick;

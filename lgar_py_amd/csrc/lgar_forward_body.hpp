@@ -262,9 +262,8 @@ __device__ __forceinline__ void forward_lane(const LGAR_KARG KArgs<R> *ap, size_
       precip_ahead = a.precip[cf];
       pet_ahead = a.pet[cf];
     }
-#ifndef LGAR_DEVSIM
-    asm volatile("" : "+v"(precip_ahead), "+v"(pet_ahead));  // (in their registers before the loop: see the loop's own note)
-#endif
+    settle_load(precip_ahead);  // (in their registers before the loop: see the loop's own note)
+    settle_load(pet_ahead);
   }
   for (int t = 0; t < T; t++) {
     ap = launder(ap);
@@ -290,13 +289,12 @@ __device__ __forceinline__ void forward_lane(const LGAR_KARG KArgs<R> *ap, size_
     }
     if (any_lane(active) == 0ull) continue;
     if (active) col.forward(precip, pet);
-#ifndef LGAR_DEVSIM
     if constexpr (coop_mode(MODE)) {
       // the forcing loaded a step ahead is taken into its registers HERE, before this step's stores are issued: loads and
       // stores share one counter, and a wait for the load placed after the stores would wait for the stores as well
-      asm volatile("" : "+v"(precip_ahead), "+v"(pet_ahead));
+      settle_load(precip_ahead);
+      settle_load(pet_ahead);
     }
-#endif
     const R acc[LGAR_NACC] = {col.a_precip, col.a_pet, col.a_aet, col.a_infil, col.a_runoff,
                               col.a_perc, col.a_giuh, col.a_disch, col.ponded_water, col.ending_volume};
     if (active && leader) {

@@ -68,15 +68,33 @@ __device__ __forceinline__ void tangent_lane(const LGAR_KARG TArgs<R> *ap, size_
   bool handed_over = false;
   const size_t Nf = (size_t)a.Nf;
   const size_t cf = (Nf == N) ? c : (c / (size_t)a.Fg) % Nf;
+  // One wave per SIMD: nothing else covers a load's latency, so a step's forcing and weights are loaded one step AHEAD (four
+  // values in registers across a step; they are taken into their registers before the step's optional store is issued --
+  // loads and stores share one counter).
+  R precip_ahead = R(0), pet_ahead = R(0), wr_ahead = R(0), wp_ahead = R(0);
+  if (a.T > 0) {
+    precip_ahead = a.precip[cf];
+    pet_ahead = a.pet[cf];
+    if (a.w_runoff) wr_ahead = a.w_runoff[cf];
+    if (a.w_perc) wp_ahead = a.w_perc[cf];
+  }
   for (int t = 0; t < a.T; t++) {
-    const size_t o = (size_t)t * Nf + cf;
     if (!a.chain_last && col.nf + a.G.nsub > FMAX) {
       handed_over = true;  // could outgrow this kernel's front capacity: the next kernel redoes this column
       break;
     }
-    col.forward(S(a.precip[o]), S(a.pet[o]));
-    if (a.w_runoff) grad += a.w_runoff[o] * col.a_runoff.d;
-    if (a.w_perc) grad += a.w_perc[o] * col.a_perc.d;
+    const R precip = precip_ahead, pet = pet_ahead, wr = wr_ahead, wp = wp_ahead;
+    {
+      const size_t o = (size_t)((t + 1 < a.T) ? t + 1 : t) * Nf + cf;
+      precip_ahead = a.precip[o];
+      pet_ahead = a.pet[o];
+      if (a.w_runoff) wr_ahead = a.w_runoff[o];
+      if (a.w_perc) wp_ahead = a.w_perc[o];
+    }
+    col.forward(S(precip), S(pet));
+    settle_load(precip_ahead); settle_load(pet_ahead); settle_load(wr_ahead); settle_load(wp_ahead);
+    if (a.w_runoff) grad += wr * col.a_runoff.d;
+    if (a.w_perc) grad += wp * col.a_perc.d;
     if (a.tangent_runoff) a.tangent_runoff[(size_t)t * N + c] = col.a_runoff.d;
     col.drain();
   }
