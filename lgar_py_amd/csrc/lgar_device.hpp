@@ -343,6 +343,7 @@ __device__ __forceinline__ void geff_shared_blocks(const LayerK<S> &l, const S &
 // same operands, only once per group instead of once per lane.
 #define LGAR_COOP_TAB 128      /* most trapezoid intervals a cooperating job may have (LgarDims.nint; 120 in every bundled config) */
 #define LGAR_COOP_TAB_ROW 130  /* doubles per group's table in LDS: padded so that the groups' tables start on different banks */
+#define LGAR_COOP_PAIR_LANES 12 /* groups of at least this many lanes take two moving fronts at a time (Column::calc_dzdt_pairs) */
 // (r: my place in the group.  The last group of a wavefront also takes the lanes left over when `lanes` does not divide 64:
 // their r >= lanes; they evaluate no node -- a node's table slot must be read as a head and rewritten by ONE lane -- and take
 // part in everything else.)
@@ -419,8 +420,8 @@ __device__ __forceinline__ void geff_nodes_cooperative(const LayerK<double> &l, 
   }
   lds_exchange_point();
   LGAR_MEASURE_POINT(CLK, 13)
-  // 2. nodes, 3. terms: two per lane and round, four when that still leaves several rounds
-  if (nint > 4 * lanes) geff_coop_node_rounds<4>(l, nm1, half_m, k_sat1, k1, hdh, nint, lanes, tab, r);
+  // 2. nodes, 3. terms: two per lane and round, four when two would take more than one round
+  if (nint > 2 * lanes) geff_coop_node_rounds<4>(l, nm1, half_m, k_sat1, k1, hdh, nint, lanes, tab, r);
   else geff_coop_node_rounds<2>(l, nm1, half_m, k_sat1, k1, hdh, nint, lanes, tab, r);
   lds_exchange_point();
   LGAR_MEASURE_POINT(CLK, 15)
@@ -1955,8 +1956,114 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
   // on the way, and the k-th moving front of every column meets the others' k-th in one evaluation of the trapezoid --
   // columns whose moving fronts sit at different indices (one has crossed into the next layer, another has two fronts
   // above a boundary) would otherwise take turns.  The fronts' dz/dt do not depend on one another, so the order is free.
+  // Cooperating lanes, groups of at least LGAR_COOP_PAIR_LANES: TWO moving fronts at a time.  A trapezoid's cost on a lone wave
+  // is its dependent chains -- the two pows that open it, the 120 additions of its heads, the 120 of its sum -- not its nodes,
+  // and most steps have two moving fronts: the lower half of the group takes one front, the upper half the other, through
+  // the same instruction stream (each half with its own front's layer, thetas and psi as operands, its own row of the group's
+  // LDS table, its lanes numbered from 0), and the halves then exchange Geff and the conductivities that rode along.  Every
+  // value is computed exactly as the one-front path computes it.  Returns the index the one-front loop resumes after (it
+  // finishes a last unpaired front, and everything when there is no pair).
+  __device__ __forceinline__ int calc_dzdt_pairs(S h_p) {
+    const int hl = share_lanes >> 1;
+    const bool upper = coop_rank >= hl;
+    const int r2 = upper ? coop_rank - hl : coop_rank;
+    R *tab2 = xchg + (upper ? LGAR_COOP_TAB_ROW : 0);
+    int i = -1;
+    auto next_moving = [&]() {  // the one-front loop's scan: fronts that need no Geff are finished on the way
+      while (++i < nf - 1) {
+        if (F.bottom(i)) { F.DZ(i) = S(R(0.0)); continue; }
+        const bool top = F.layer(i) == 0;
+        if (top && val(F.TH(i + 1)) > val(F.TH(i))) status |= LGAR_ST_THETA_ORDER;  // Layer.py:1206-1208
+        if (val(F.TH(i) - F.TH(i + 1)) > R(0.0)) return i;
+        F.DZ(i) = S(R(0.0));
+      }
+      return -1;
+    };
+    for (;;) {
+      const int ia = next_moving();
+      if (ia < 0) return i;
+      const int ib = next_moving();
+      const int ka = F.layer(ia), kb = (ib >= 0) ? F.layer(ib) : 0;
+      // no pair, or a half too small for a front's riders: the one-front loop takes over at front ia (the fronts behind it are
+      // done; the scan's side effects beyond it are idempotent)
+      if (ib < 0 || hl < 5 + ((ka > kb) ? ka : kb)) return ia - 1;
+      const int im = upper ? ib : ia;
+      const int k = upper ? kb : ka;
+      const LayerK<S> lk = pick(P, k);
+      const S theta_1 = F.TH(im + 1), theta_2 = F.TH(im);
+      CoopRiders riders;
+      {
+        const int e = r2 - 5;  // my layer above (lanes 5 .. 5 + k - 1 of my half)
+        LayerK<S> le = lk;
+        S th_e = theta_2;
+#pragma unroll
+        for (int j = 0; j < NL - 1; j++) {
+          const bool mine = (e == j) && (j < k);
+          le.alpha = choose(mine, P.alpha[j], le.alpha); le.n = choose(mine, P.n[j], le.n); le.m = choose(mine, P.m[j], le.m);
+          le.inv_m = choose(mine, P.inv_m[j], le.inv_m); le.ksat = choose(mine, P.ksat[j], le.ksat);
+          le.te = choose(mine, P.te[j], le.te); le.tr = choose(mine, P.tr[j], le.tr);
+        }
+        if (ka > 0 || kb > 0) {
+          const S tl = theta_from_h<S, POL>(le, F.PS(im));
+          th_e = choose(e >= 0 && e < k, tl, th_e);
+        }
+        riders.n = 1 + k;
+        riders.l = le;
+        riders.se = se_from_theta(le, th_e);
+#pragma unroll
+        for (int q = 0; q < LGAR_LMAX; q++) riders.k[q] = R(1.0);
+      }
+      LGAR_COUNT_GEFF_CALL(1)
+      LGAR_COUNT_GEFF_CALL(1)
+      const S g_mine = geff_fused<S>(lk, theta_1, theta_2, G->nint, tab2, hl, r2, &riders);
+      // the halves exchange what they found (every lane of a half stores the same values)
+      tab2[0] = g_mine;
+#pragma unroll
+      for (int q = 0; q < NL; q++) tab2[1 + q] = riders.k[q];
+      lds_exchange_point();
+      S g2[2];
+      R kk[2][NL];
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        g2[h] = xchg[h * LGAR_COOP_TAB_ROW];
+#pragma unroll
+        for (int q = 0; q < NL; q++) kk[h][q] = xchg[h * LGAR_COOP_TAB_ROW + 1 + q];
+      }
+      lds_exchange_point();
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int f = h ? ib : ia;
+        const int kf = h ? kb : ka;
+        const LayerK<S> lf = pick(P, kf);
+        const S g = g2[h];
+        S ki = kk[h][0];
+        if (f == 0 && new_front_frozen) ki = ki * G->frozen;
+        if (is_nan(val(g))) status |= LGAR_ST_NAN;
+        const S delta_theta = F.TH(f) - F.TH(f + 1);
+        S dzdt;
+        if (kf == 0) {
+          dzdt = dv<POL>(S(R(1.0)), delta_theta) * (dv<POL>(lf.ksat * (g + h_p), F.Z(f)) + ki);
+        } else {
+          S den = S(R(0.0)) + dv<POL>(F.Z(f) - cum_prev(kf), ki);
+#pragma unroll
+          for (int j = 0; j < NL - 1; j++)
+            if (j < kf) {
+              S pt = (j != 0) ? P.cum[(j > 0) ? j - 1 : 0] : S(R(0.0));
+              den = den + dv<POL>(P.cum[j] - pt, S(kk[h][1 + j]));
+            }
+          dzdt = dv<POL>(S(R(1.0)), delta_theta) * (dv<POL>(F.Z(f), den) + dv<POL>(lf.ksat * (g + h_p), F.Z(f)));
+        }
+        F.DZ(f) = dzdt;
+      }
+    }
+  }
+
   __device__ __forceinline__ void calc_dzdt(S h_p) {
     int i = -1;
+    if constexpr (COOP) {
+      // (a group of 8 or more lanes owns TWO rows of the exchange table: lgar_kernels_nl.hip)
+      if (share_lanes >= LGAR_COOP_PAIR_LANES && !G->closed_form) i = calc_dzdt_pairs(h_p);
+    }
     for (;;) {
       // advance to the next front that moves
       bool found = false;

@@ -84,7 +84,9 @@ __global__ __launch_bounds__(WAVE, (Occupancy<R, CAP>::waves)) void lgar_forward
         const int rank = lane - group * coop;
         const size_t c0 = (size_t)blk * cpb + group;
         const bool live = c0 < N;
-        forward_lane<R, NL, CAP, MODE>(ap, live ? c0 : N - 1, live, lane, lds, rank == 0, &coop_lds.tab[group][0], group, rank);
+        // (a wave of at most 8 columns leaves every group two rows of the exchange table: Column::calc_dzdt_pairs)
+        const int rows = (cpb <= LGAR_COOP_GROUPS / 2) ? 2 : 1;
+        forward_lane<R, NL, CAP, MODE>(ap, live ? c0 : N - 1, live, lane, lds, rank == 0, &coop_lds.tab[group * rows][0], group, rank);
         continue;
       }
     }
