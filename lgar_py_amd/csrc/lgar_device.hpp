@@ -543,10 +543,12 @@ __device__ __forceinline__ S geff_fused(const LayerK<S> &l, S theta1, S theta2, 
   }
 #endif
   if (!ends_done) {
+    LGAR_MEASURE_POINT(CLK, 25)
     h_i = h_from_se(l, se_i);
     h_f = h_from_se(l, se_f);
     k_sat1 = k_from_se(l, S(R(1.0)));
     k1 = k_from_se(l, se_i);
+    LGAR_MEASURE_POINT(CLK, 26)
   }
   const S dh = (h_f - h_i) / R(nint);
   const S hdh = dh / R(2.0);
@@ -583,8 +585,10 @@ __device__ __forceinline__ S geff_fused(const LayerK<S> &l, S theta1, S theta2, 
   }
   if constexpr (sizeof(S) != sizeof(R) && sizeof(R) == 8) {
     if (xchg != nullptr && coop >= 2 && n_safe >= coop) {  // coop: the W lanes that share this column (LgarDims.tangent_share)
+      LGAR_MEASURE_POINT(CLK, 27)
       geff_shared_blocks(l, nm1, half_m, h2, dh, hdh, g, k1, n_safe / coop, coop, xchg);
       i = (n_safe / coop) * coop;
+      LGAR_MEASURE_POINT(CLK, 28)
     }
   }
 
@@ -620,6 +624,7 @@ __device__ __forceinline__ S geff_fused(const LayerK<S> &l, S theta1, S theta2, 
   // reference raises ValueError there, physics/utils.py:25-27) must still surface as NaN for the status word
   const bool outside = is_nan(val(h_i)) || is_nan(val(h_f));
   const S res = ab(g / l.ksat);
+  LGAR_MEASURE_POINT(CLK, 29)
   return outside ? res + (h_i + h_f) : res;
 }
 // fp32 Geff, lean form (what bench.py measures).  Per node, with x = alpha h and K_r = K / Ksat (Ksat cancels in

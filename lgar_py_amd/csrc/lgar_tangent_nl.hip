@@ -114,6 +114,16 @@ int launch_tangent_nl(const LgarDims *dims, const LgarParams *params, const Lgar
   return LGAR_E_ARG;
 }
 
+#if defined(LGAR_MEASURE) && defined(LGAR_CLOCKS)
+// measurement builds: the cycle attribution of this translation unit's kernels (lgar_measure.hpp LGAR_POINT_CLK)
+extern "C" int lgar_debug_clocks_tangent(unsigned long long *out, int reset) {
+  unsigned long long z[64] = {0};
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(lgar_dbg_clk), sizeof(z)) != hipSuccess) return -1;
+  if (reset && hipMemcpyToSymbol(HIP_SYMBOL(lgar_dbg_clk), z, sizeof(z)) != hipSuccess) return -1;
+  return 0;
+}
+#endif
+
 template int launch_tangent_nl<LGAR_NL>(const LgarDims *, const LgarParams *, const LgarParams *, const LgarForcing *,
                                         const void *, const void *, void *, void *, int32_t *, int, hipStream_t, unsigned *);
 

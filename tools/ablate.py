@@ -39,6 +39,7 @@ VARIANTS = {
     "cf_relaxocc": ["-mllvm", "-amdgpu-schedule-relaxed-occupancy=true"], "cf_nopostsched": ["-mllvm", "-enable-post-misched=0"],
     "cf_nounroll": ["-fno-unroll-loops"], "cf_metricbias": ["-mllvm", "-amdgpu-schedule-metric-bias=30"], "cf_trackers": ["-mllvm", "-amdgpu-use-amdgpu-trackers"],
     "cf_iterative": ["-mllvm", "-amdgpu-sched-strategy=iterative-minreg"], "cf_nohighrp": ["-mllvm", "-amdgpu-disable-unclustered-high-rp-reschedule"],
+    "tan_clocks": ["-DLGAR_CLOCKS"],  # cycle attribution of the tangent kernel: tools/tangent_clocks.py
     "tan_base": [], "tan_maxilp": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"], "tan_f32w1": ["-DLGAR_TAN_F32_WAVES=1"],
     # mixed-precision kernels only (quick to build): experiments on geff_mixed, run with `ablate.py run mix`
     "mx_base": ["-DLGAR_ONLY_MIXED"], "mx_general": ["-DLGAR_ONLY_MIXED", "-DLGAR_GEFFM_GENERAL_ONLY"],
