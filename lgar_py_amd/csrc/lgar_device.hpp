@@ -321,15 +321,19 @@ template <typename S> __device__ __forceinline__ S geff_node(const LayerK<S> &l,
 // directions: each lane evaluates one node of a block and the W exchange the values.
 template <typename S>
 __device__ __forceinline__ void geff_shared_blocks(const LayerK<S> &l, const S &nm1, const S &half_m, S &h2, const S &dh, const S &hdh, S &g,
-                                                   S &k1, int nb, int W, real_t<S> *xchg) {
+                                                   S &k1, int nb, int W, real_t<S> *xchg, int rem) {
   (void)xchg;
-  for (int j = 0; j < W * nb; j++) {
+  for (int j = 0; j < W * nb + rem; j++) {
     const S k2 = geff_node(l, nm1, half_m, h2);
     g = g + ((k1 + k2) * hdh);
     k1 = k2;
     h2 = h2 + dh;
   }
 }
+// (sizes of the cooperating lanes' exchange table: plain constants, the simulator's build sees them too)
+#define LGAR_COOP_TAB 128      /* most trapezoid intervals a cooperating job may have (LgarDims.nint; 120 in every bundled config) */
+#define LGAR_COOP_TAB_ROW 130  /* doubles per group's table in LDS: padded so that the groups' tables start on different banks */
+#define LGAR_COOP_PAIR_LANES 12 /* groups of at least this many lanes take two moving fronts at a time (Column::calc_dzdt_pairs) */
 #ifndef LGAR_DEVSIM
 // The trapezoid's interior for COOPERATING lanes (forward kernels on jobs too small to fill the chip, LgarDims.forward_lanes):
 // the `lanes` lanes of an aligned group all carry the SAME column -- same values, same branches.  `tab` is the group's table
@@ -341,9 +345,6 @@ __device__ __forceinline__ void geff_shared_blocks(const LayerK<S> &l, const S &
 //   4. every lane adds the 120 terms up in order.
 // Heads, node values, terms and the sum are those of the plain loop bit for bit: each goes through the same operations on the
 // same operands, only once per group instead of once per lane.
-#define LGAR_COOP_TAB 128      /* most trapezoid intervals a cooperating job may have (LgarDims.nint; 120 in every bundled config) */
-#define LGAR_COOP_TAB_ROW 130  /* doubles per group's table in LDS: padded so that the groups' tables start on different banks */
-#define LGAR_COOP_PAIR_LANES 12 /* groups of at least this many lanes take two moving fronts at a time (Column::calc_dzdt_pairs) */
 // (r: my place in the group.  The last group of a wavefront also takes the lanes left over when `lanes` does not divide 64:
 // their r >= lanes; they evaluate no node -- a node's table slot must be read as a head and rewritten by ONE lane -- and take
 // part in everything else.)
@@ -586,8 +587,8 @@ __device__ __forceinline__ S geff_fused(const LayerK<S> &l, S theta1, S theta2, 
   if constexpr (sizeof(S) != sizeof(R) && sizeof(R) == 8) {
     if (xchg != nullptr && coop >= 2 && n_safe >= coop) {  // coop: the W lanes that share this column (LgarDims.tangent_share)
       LGAR_MEASURE_POINT(CLK, 27)
-      geff_shared_blocks(l, nm1, half_m, h2, dh, hdh, g, k1, n_safe / coop, coop, xchg);
-      i = (n_safe / coop) * coop;
+      geff_shared_blocks(l, nm1, half_m, h2, dh, hdh, g, k1, n_safe / coop, coop, xchg, n_safe % coop);
+      i = n_safe;  // (the safe nodes left over after the full blocks are one more, partial block)
       LGAR_MEASURE_POINT(CLK, 28)
     }
   }

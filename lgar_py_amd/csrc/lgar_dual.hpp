@@ -185,7 +185,7 @@ __device__ __forceinline__ Dual<R> geff_node(const LayerK<Dual<R>> &l, const Dua
 template <int WC>
 __device__ __forceinline__ void geff_shared_blocks_w(const LayerK<Dual<double>> &l, const Dual<double> &nm1, const Dual<double> &half_m,
                                                      Dual<double> &h2, const Dual<double> &dh, const Dual<double> &hdh, Dual<double> &g,
-                                                     Dual<double> &k1, int nb, int Wrt, double *xchg) {
+                                                     Dual<double> &k1, int nb, int Wrt, double *xchg, int rem) {
   const int W = WC ? WC : Wrt;
   const double LN2 = 0.6931471805599453;
   const int lane = (int)(threadIdx.x & 63u);
@@ -194,15 +194,8 @@ __device__ __forceinline__ void geff_shared_blocks_w(const LayerK<Dual<double>> 
   double s1 = 0.0, s1j = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0;  // my nodes' share of the five sums
   double a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0;                        // tangent coefficients of my latest node
   double gv = g.v, k1v = k1.v, hv = h2.v, pairsum = 0.0;
-  for (int b = 0; b < nb; b++) {
-    // the W heads by the running sum of the plain loop; mine is number r
-    double hm = hv;
-#pragma unroll
-    for (int j = 0; j < W; j++) {
-      hm = (j == r) ? hv : hm;
-      hv = hv + dh.v;
-    }
-    // my node: geff_node's value operations ...
+  // my node of a block: geff_node's value operations and the coefficients of its tangent
+  auto node = [&](double hm, double &Kv, double &c1, double &c2, double &c3, double &c4) {
     const double xv = l.alpha.v * hm;
     const double lg = lg2p(xv);
     const double Pv = ex2p(nm1.v * lg);
@@ -214,45 +207,38 @@ __device__ __forceinline__ void geff_shared_blocks_w(const LayerK<Dual<double>> 
     const double tv = 1.0 - Ps2;
     const double ks = l.ksat.v * sv;
     const double tt = tv * tv;
-    const double Kv = ks * tt;
-    // ... and the coefficients of its tangent
+    Kv = ks * tt;
     const double rc = fast_recip(xv * Av);  // one reciprocal serves 1/x and 1/A
     const double B = (2.0 * (ks * tv)) * Ps2;
     const double Wk = Kv - 2.0 * B;
     const double U = (half_m.v * (av * (rc * xv))) * Wk;
-    a1 = (rc * Av) * ((1.0 + nm1.v) * U - nm1.v * B);
-    a2 = (LN2 * lg) * (U - B);
-    a3 = (LN2 * l1) * Wk;
-    a4 = sv * tt;
-    const double jj = (double)(W * b + r);
-    s1 += a1; s1j = fma(a1, jj, s1j); s2 += a2; s3 += a3; s4 += a4;
-    // one wave = one workgroup: LDS operations of a wave complete in order, the fences only pin the compiler.
-    // (A software pipeline -- block b's values read before block b+1's node is evaluated and added up after it -- was built
-    // and measured: 4 ms SLOWER on the 100 000-column backward pass, 26 more AGPRs of shuffling for latency that is a small
-    // part of a block by now.)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    grp[r] = Kv;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    __builtin_amdgcn_wave_barrier();
+    c1 = (rc * Av) * ((1.0 + nm1.v) * U - nm1.v * B);
+    c2 = (LN2 * lg) * (U - B);
+    c3 = (LN2 * l1) * Wk;
+    c4 = sv * tt;
+  };
+  // every lane adds the first `cnt` values of a block up in order (same address in all lanes of the group: an LDS broadcast)
+  auto add_up = [&](int cnt) {
     if constexpr (WC != 0) {
       double kq[WC ? WC : 1];
 #pragma unroll
-      for (int j = 0; j < WC; j++) kq[j] = grp[j];  // same address in all lanes of the group: an LDS broadcast
+      for (int j = 0; j < WC; j++) kq[j] = grp[j];
 #pragma unroll
-      for (int j = 0; j < WC; j++) {
-        const double pr = k1v + kq[j];
-        gv = gv + (pr * hdh.v);
-        pairsum += pr;
-        k1v = kq[j];
-      }
+      for (int j = 0; j < WC; j++)
+        if (j < cnt) {  // (wave-uniform; always true in a full block)
+          const double pr = k1v + kq[j];
+          gv = gv + (pr * hdh.v);
+          pairsum += pr;
+          k1v = kq[j];
+        }
     } else {
-      for (int j0 = 0; j0 < W; j0 += 8) {  // eight reads in flight at a time
+      for (int j0 = 0; j0 < cnt; j0 += 8) {  // eight reads in flight at a time
         double kq[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) kq[j] = grp[(j0 + j < W) ? j0 + j : W - 1];
 #pragma unroll
         for (int j = 0; j < 8; j++)
-          if (j0 + j < W) {
+          if (j0 + j < cnt) {
             const double pr = k1v + kq[j];
             gv = gv + (pr * hdh.v);
             pairsum += pr;
@@ -260,7 +246,62 @@ __device__ __forceinline__ void geff_shared_blocks_w(const LayerK<Dual<double>> 
           }
       }
     }
+  };
+  // MY head: number r of the plain loop's running sum, found once; from then on every block advances it by the W additions
+  // of that running sum -- the same sequence of values (nine additions per block instead of nine compare-select-add steps)
+  double hm = hv;
+  if constexpr (WC != 0) {
+#pragma unroll
+    for (int j = 0; j < WC; j++) {
+      hm = (j == r) ? hv : hm;
+      hv = hv + dh.v;
+    }
+  } else {
+    for (int j = 0; j < W; j++) {
+      hm = (j == r) ? hv : hm;
+      hv = hv + dh.v;
+    }
+  }
+  // one wave = one workgroup: LDS operations of a wave complete in order, the fences only pin the compiler.
+  // (A software pipeline -- block b's values read before block b+1's node is evaluated and added up after it -- was built
+  // and measured: 4 ms SLOWER on the 100 000-column backward pass, 26 more AGPRs of shuffling for latency that is a small
+  // part of a block by now.)
+  for (int b = 0; b < nb; b++) {
+    double Kv;
+    node(hm, Kv, a1, a2, a3, a4);
+    if constexpr (WC != 0) {
+#pragma unroll
+      for (int j = 0; j < WC; j++) hm = hm + dh.v;
+    } else {
+      for (int j = 0; j < W; j++) hm = hm + dh.v;
+    }
+    const double jj = (double)(W * b + r);
+    s1 += a1; s1j = fma(a1, jj, s1j); s2 += a2; s3 += a3; s4 += a4;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    grp[r] = Kv;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    add_up(W);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // the next block's store stays behind these loads
+    __builtin_amdgcn_wave_barrier();
+  }
+  // the `rem` < W safe nodes left over after the full blocks: one more block in which only the first `rem` lanes of the group
+  // have a node (the others evaluate one for nothing and leave it out of every sum)
+  if (rem > 0) {
+    double Kv, t1, t2, t3, t4;
+    node(hm, Kv, t1, t2, t3, t4);
+    for (int j = 0; j < rem; j++) hm = hm + dh.v;
+    if (r < rem) {
+      a1 = t1; a2 = t2; a3 = t3; a4 = t4;
+      const double jj = (double)(W * nb + r);
+      s1 += a1; s1j = fma(a1, jj, s1j); s2 += a2; s3 += a3; s4 += a4;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    grp[r] = Kv;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    add_up(rem);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
   }
   // the five sums over all block nodes, and the last node's coefficients (the group's last lane evaluated it)
@@ -268,6 +309,7 @@ __device__ __forceinline__ void geff_shared_blocks_w(const LayerK<Dual<double>> 
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   red[0 * W + r] = s1; red[1 * W + r] = s1j; red[2 * W + r] = s2; red[3 * W + r] = s3; red[4 * W + r] = s4;
   red[5 * W + r] = a1; red[6 * W + r] = a2; red[7 * W + r] = a3; red[8 * W + r] = a4;
+  if (r == 0) red[9 * W] = hm;  // (the group's padding slot) the running sum after the last block node: lane 0's head by now
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   __builtin_amdgcn_wave_barrier();
   double S[5];
@@ -278,11 +320,13 @@ __device__ __forceinline__ void geff_shared_blocks_w(const LayerK<Dual<double>> 
     for (int j = 1; j < W; j++) t += red[v * W + j];
     S[v] = t;
   }
-  const double L1 = red[5 * W + W - 1], L2 = red[6 * W + W - 1], L3 = red[7 * W + W - 1], L4 = red[8 * W + W - 1];
+  const int last = (rem > 0) ? rem - 1 : W - 1;  // the lane that evaluated the last block node
+  const double L1 = red[5 * W + last], L2 = red[6 * W + last], L3 = red[7 * W + last], L4 = red[8 * W + last];
+  hv = red[9 * W];
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // a later call's stores stay behind these loads
   __builtin_amdgcn_wave_barrier();
   // sum of dK over the block nodes and dK of the last one, for MY direction
-  const double m = (double)(W * nb);
+  const double m = (double)(W * nb + rem);
   // d(alpha h_j) = c0 + j c1 with the node's head h_j = h_0 + j dh.  c0 and c1 are formed FIRST: for the alpha direction
   // alpha h does not depend on alpha at all (h = f(Se) / alpha), the two products in each cancel, and they must cancel before
   // anything is summed -- grouped by input instead (d alpha sum A1 h + alpha sum A1 dh_j) the big sums cancel to ~1e-8 of the
@@ -298,10 +342,10 @@ __device__ __forceinline__ void geff_shared_blocks_w(const LayerK<Dual<double>> 
 }
 __device__ __forceinline__ void geff_shared_blocks(const LayerK<Dual<double>> &l, const Dual<double> &nm1, const Dual<double> &half_m,
                                                    Dual<double> &h2, const Dual<double> &dh, const Dual<double> &hdh, Dual<double> &g,
-                                                   Dual<double> &k1, int nb, int W, double *xchg) {
+                                                   Dual<double> &k1, int nb, int W, double *xchg, int rem) {
   // 9 = the 3 x L parameters of a three-layer column (BASELINE configs[4]); other widths run the generic loops
-  if (W == 9) geff_shared_blocks_w<9>(l, nm1, half_m, h2, dh, hdh, g, k1, nb, W, xchg);
-  else geff_shared_blocks_w<0>(l, nm1, half_m, h2, dh, hdh, g, k1, nb, W, xchg);
+  if (W == 9) geff_shared_blocks_w<9>(l, nm1, half_m, h2, dh, hdh, g, k1, nb, W, xchg, rem);
+  else geff_shared_blocks_w<0>(l, nm1, half_m, h2, dh, hdh, g, k1, nb, W, xchg, rem);
 }
 #endif
 template <> __device__ __forceinline__ Dual<double> geff<Dual<double>>(const LayerK<Dual<double>> &l, Dual<double> t1,
