@@ -196,10 +196,11 @@ static int forward_typed(const LgarDims *dims, const LgarParams *params, LgarSta
   // small jobs (under one wave per SIMD) gain nothing from occupancy and start at the full capacity
   const int need = NL + dims->num_subcycles + 2;
   // Jobs that cannot fill the chip (the reference's own use is ONE column, agents/DifferentiableLGAR.py:117-125): in double
-  // precision every column gets 8..64 cooperating lanes that split the Geff trapezoid's nodes and the pows that open it
-  // (lgar_device.hpp geff_nodes_cooperative / geff_ends_cooperative).  Results are bit for bit those of one lane per column.
-  // Such a job runs the 32-front kernel directly (MODE 4: front table and exchange table once per GROUP of lanes, 37 KB of LDS
-  // per wave, one wave per SIMD): no capacity chain, no hand-over.
+  // precision every column gets 4..64 cooperating lanes that split the Geff trapezoid's nodes, the pows that open it and the
+  // front sweep's independent evaluations (lgar_device.hpp geff_nodes_cooperative / geff_ends_cooperative / coop_sweep_thetas /
+  // calc_dzdt_pairs).  Results are bit for bit those of one lane per column.  Such a job runs the 32-front kernel directly
+  // (MODE 4: front table and exchange table once per GROUP of lanes, 34 KB of LDS per wave, one wave per SIMD): no capacity
+  // chain, no hand-over.
   a.coop = cooperating_lanes<R>(dims, wave_slots(1));
   const bool tiny = (grid <= 1024u && dims->search_mode != 2) || a.coop > 1;  // search_mode 2: chain forced (tests)
   int caps[3], nc = 0;
