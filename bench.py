@@ -341,7 +341,7 @@ def main():
                  ("alpha", "n", "ksat", "theta_e", "theta_r", "thickness")}
             sc = torch.ones(n_cols, dtype=torch.float64, device=dev)
             eng = lg.LgarEngine(P["alpha"], P["n"], P["ksat"], P["theta_e"], P["theta_r"], P["thickness"],
-                                dt_h=1.0, ponded_depth_max=2.0, dtype=dt, device=dev)
+                                dt_h=1.0, ponded_depth_max=2.0, dtype=dt, device=dev, **eng_kw)
         else:
             f = W.synth1_forcing(args.tile)
             P = W.perturbed_columns(n_cols, seed=seed_rank)  # rank r holds columns [r*N, (r+1)*N) of the job; seed = shard index
@@ -568,16 +568,34 @@ def main():
                                 "workload": "BASELINE configs[1]: 10k replicated Phillipsburg columns x 3000 hourly steps, fp64 "
                                             "(157 waves of columns on 1024 SIMDs: bound by the time ONE wave needs for 3000 steps, "
                                             "not a throughput figure; the library gives every column the cooperating lanes that "
-                                            "keep the job at one wave per SIMD -- 6 here, 150 -> 88 ms)"}
-            del ec, pc, qc
+                                            "keep the job at one wave per SIMD -- 6 here, 150 -> 82 ms)"}
+            del ec
+            # ... and in the mixed-precision mode (fp64 state, fp32-transcendental trapezoid nodes): its four-node groups are split
+            # over the column's lanes as well (bit for bit the mixed mode with one lane per column)
+            em, _, _, _ = make_workload("phillipsburg", 10_000, torch.float64, 0, geff_precision="f32")
+            ms = []
+            for _ in range(2):
+                em.reset()
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                em.forward(pc, qc, series=("runoff", "percolation"), check=False)
+                b.record()
+                torch.cuda.synchronize()
+                ms.append(a.elapsed_time(b))
+            subs["configs1"]["mixed_precision"] = {"kernel_ms": min(ms), "value": 10_000 * Tc / (min(ms) * 1e-3),
+                                                   "lanes_per_column": em.cooperating_lanes(),
+                                                   "dtype": "f64 state / f32 trapezoid nodes"}
+            del em, pc, qc
             # the reference's own use: ONE column (agents/DifferentiableLGAR.py:117-125), 3000 hourly rows in one launch, with
             # one lane and with the library's choice of cooperating lanes (64 for a job this small; same results bit for bit)
             one = {}
-            for label, lanes in (("one_lane", 1), ("cooperating_lanes", 0)):
+            for label, lanes, prec in (("one_lane", 1, "native"), ("cooperating_lanes", 0, "native"),
+                                       ("cooperating_lanes_mixed_precision", 0, "f32")):
                 g1 = np.load(os.path.join(ROOT, "tests", "golden", "phil_hourly_3000.npz"))
                 P1 = W.PHILLIPSBURG
                 e1 = lg.LgarEngine(*[P1[k] for k in ("alpha", "n", "ksat", "theta_e", "theta_r", "thickness")], n_columns=1,
-                                   dt_h=1.0, ponded_depth_max=2.0, dtype=torch.float64, device=dev, forward_lanes=lanes)
+                                   dt_h=1.0, ponded_depth_max=2.0, dtype=torch.float64, device=dev, forward_lanes=lanes,
+                                   geff_precision=prec)
                 p1 = torch.tensor(g1["forcing"][:, 0:1], device=dev).contiguous()
                 q1 = torch.tensor(g1["forcing"][:, 1:2], device=dev).contiguous()
                 ms = []
@@ -593,7 +611,7 @@ def main():
             subs["single_column"] = dict(one, columns=1, timesteps=int(p1.shape[0]), dtype="f64",
                                          workload="the bundled Phillipsburg column x 3000 hourly steps in one launch (the "
                                                   "reference: 12.9 steps/s); jobs under one wave per SIMD give every column "
-                                                  "8..64 lanes that split the Geff trapezoid")
+                                                  "4..64 lanes that split the Geff trapezoid and the front sweep")
             # BASELINE configs[4]: 100 000-column vG parameter ensemble, forward + backward (autograd through the HIP
             # kernels: 9 parameter directions as one tangent launch), loss = mean of runoff^2
             from lgar_py_amd.autograd import lgar_series

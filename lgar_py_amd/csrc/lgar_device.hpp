@@ -792,8 +792,13 @@ __device__ __forceinline__ void mixed_end(const LayerK<double> &l, double se, do
 }
 // The interior of the mixed-precision trapezoid and its closing formula, given both heads, K_r of both end nodes and K_r at
 // Se == 1 (see geff_mixed / geff_mixed_heads for where they come from).
+// COOPERATE (cooperating lanes, MODE 6): the lanes of a group carry the same column; lane r of `lanes` evaluates the
+// four-node groups r, r + lanes, ... in the general, checked form -- the value every form gives a group, bit for bit -- and
+// leaves each group's sum in the group's LDS table `tab`; every lane then adds the groups up in order, as the loops below do.
+template <bool COOPERATE = false>
 __device__ __forceinline__ double geff_mixed_core(const LayerK<double> &l, double h_i, double h_f, double k0, double kn_own, double ksat1,
-                                                  int nint) {
+                                                  int nint, double *tab = nullptr, int lanes = 0, int r = 0) {
+  (void)tab; (void)lanes; (void)r;
   const float ksat1f = (float)ksat1;
   const double dh = (h_f - h_i) / double(nint);
   const double x0 = l.alpha * h_i, dx = l.alpha * dh, xcut = 0.1 * l.alpha;
@@ -806,7 +811,7 @@ __device__ __forceinline__ double geff_mixed_core(const LayerK<double> &l, doubl
   int safe = (jf > 0.0) ? ((jf < double(M)) ? int(jf) : M) : 0;  // NaN (dx == 0, or a head outside the domain) -> 0
   safe >>= 1;
   int safe_pairs = pairs;
-  if (any_lane(safe < pairs) != 0ull) {
+  if (!COOPERATE && any_lane(safe < pairs) != 0ull) {
     safe_pairs = 0;
     for (int bit = 64; bit; bit >>= 1) {
       const int cand = safe_pairs + bit;
@@ -891,7 +896,7 @@ __device__ __forceinline__ double geff_mixed_core(const LayerK<double> &l, doubl
   // node depends on the one before it, and a dependent operation cannot issue in the slot after its producer (the compiler
   // fills those slots with s_nop when it has nothing else) -- a wave that walks one chain after the other spends half its issue
   // slots waiting.  Same operations on the same operands as LGAR_GEFFM_PAIR, pair by pair: the same values bit for bit.
-#define LGAR_GEFFM_GROUP(CUT, KIND)                                                         \
+#define LGAR_GEFFM_GROUP(CUT, KIND, SINK)                                                   \
   {                                                                                         \
     const f32x2 xha = __builtin_elementwise_fma(ja, dxh2, x0h2), xhb = __builtin_elementwise_fma(jb, dxh2, x0h2); \
     const f32x2 xla = __builtin_elementwise_fma(ja, dxl2, x0l2), xlb = __builtin_elementwise_fma(jb, dxl2, x0l2); \
@@ -942,8 +947,9 @@ __device__ __forceinline__ double geff_mixed_core(const LayerK<double> &l, doubl
     }                                                                                       \
     const f32x2 ka = sa * ta;                                                               \
     const f32x2 kb = __builtin_elementwise_fma(sb, tb, ka);                                 \
-    sum = sum + (double)(kb.x + kb.y);                                                      \
+    SINK((double)(kb.x + kb.y))                                                             \
   }
+#define LGAR_GEFFM_TO_SUM(v) sum = sum + (v);
   // Which of the two forms of t a node takes depends on 2^E > 7/8, and E rises monotonically with x = alpha h: the series
   // region is a PREFIX of the nodes (x > x_thr, the dry end), the difference region a suffix.  x_thr -- (1 + x^-n)^-m = 7/8 --
   // is a function of the layer's n alone; a node further than 1e-4 (relative) from it is decided whatever the rounding of
@@ -952,7 +958,38 @@ __device__ __forceinline__ double geff_mixed_core(const LayerK<double> &l, doubl
   // form up to the smallest of the former, the difference-only form from the largest of the latter, the general form in
   // between -- every node gets exactly the value the general form alone would give it (bit for bit: tests/devsim).
   int ser_pairs = 0, dir_pair = pairs + 1;  // (a reversed or empty range, or NaN: the general form throughout)
-  if (dx < 0.0) {
+  if constexpr (COOPERATE) {
+    const int ngroups = pairs >> 1;  // the full groups of four interior nodes
+    lds_exchange_point();            // (earlier loads of the table stay in front of these stores)
+    for (int q = (r < lanes) ? r : ngroups; q < ngroups; q += lanes) {
+      const float j0 = (float)(4 * q);
+      ja = f32x2{j0 + 1.0f, j0 + 2.0f};
+      jb = f32x2{j0 + 3.0f, j0 + 4.0f};
+#define LGAR_GEFFM_TO_TAB(v) tab[q] = (v);
+      LGAR_GEFFM_GROUP(true, 0, LGAR_GEFFM_TO_TAB)
+#undef LGAR_GEFFM_TO_TAB
+    }
+    lds_exchange_point();
+    {
+      int q0 = 0;
+      for (; q0 + 8 <= ngroups; q0 += 8) {
+        double tq[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) tq[j] = tab[q0 + j];  // same address in every lane of the group: a broadcast
+#pragma unroll
+        for (int j = 0; j < 8; j++) sum = sum + tq[j];
+      }
+      for (; q0 < ngroups; q0++) sum = sum + tab[q0];
+    }
+    lds_exchange_point();
+    it = 2 * ngroups;
+    {
+      const float j0 = (float)(4 * ngroups);
+      ja = f32x2{j0 + 1.0f, j0 + 2.0f};
+      jb = f32x2{j0 + 3.0f, j0 + 4.0f};
+    }
+  }
+  if (!COOPERATE && dx < 0.0) {
     const float x_thr = pw(pw(8.0f / 7.0f, (float)l.inv_m) - 1.0f, -(float)l.inv_n);
     const double js_f = (x0 - (double)(x_thr * 1.0001f)) / -dx - 1.0;  // nodes 1 .. js: x_j > x_thr (1 + 1e-4)
     const int js = (js_f > 0.0) ? ((js_f < double(M)) ? int(js_f) : M) : 0;
@@ -963,7 +1000,7 @@ __device__ __forceinline__ double geff_mixed_core(const LayerK<double> &l, doubl
   }
   LGAR_MEASURE_POINT(GEFFM_GENERAL_ONLY, ser_pairs, dir_pair, pairs)
   int ser_all = safe_pairs;  // the wavefront's: min of ser_pairs (at most safe_pairs), max of dir_pair
-  if (any_lane(ser_pairs < ser_all) != 0ull) {
+  if (!COOPERATE && any_lane(ser_pairs < ser_all) != 0ull) {
     ser_all = 0;
     for (int bit = 64; bit; bit >>= 1) {
       const int cand = ser_all + bit;
@@ -971,19 +1008,22 @@ __device__ __forceinline__ double geff_mixed_core(const LayerK<double> &l, doubl
     }
   }
   int dir_all = 0;
+  if constexpr (!COOPERATE) {
   for (int bit = 64; bit; bit >>= 1) {
     const int cand = dir_all + bit;
     if (any_lane(dir_pair >= cand) != 0ull) dir_all = cand;
   }
-  for (; it + 1 < ser_all; it += 2, ja = ja + four2, jb = jb + four2) LGAR_GEFFM_GROUP(false, 1)
+  for (; it + 1 < ser_all; it += 2, ja = ja + four2, jb = jb + four2) LGAR_GEFFM_GROUP(false, 1, LGAR_GEFFM_TO_SUM)
   const int it_a = it;
-  for (; it + 1 < safe_pairs && it < dir_all; it += 2, ja = ja + four2, jb = jb + four2) LGAR_GEFFM_GROUP(false, 0)
+  for (; it + 1 < safe_pairs && it < dir_all; it += 2, ja = ja + four2, jb = jb + four2) LGAR_GEFFM_GROUP(false, 0, LGAR_GEFFM_TO_SUM)
   const int it_b = it;
-  for (; it + 1 < safe_pairs; it += 2, ja = ja + four2, jb = jb + four2) LGAR_GEFFM_GROUP(false, 2)
+  for (; it + 1 < safe_pairs; it += 2, ja = ja + four2, jb = jb + four2) LGAR_GEFFM_GROUP(false, 2, LGAR_GEFFM_TO_SUM)
   const int it_c = it;
-  for (; it + 1 < pairs; it += 2, ja = ja + four2, jb = jb + four2) LGAR_GEFFM_GROUP(true, 0)
+  for (; it + 1 < pairs; it += 2, ja = ja + four2, jb = jb + four2) LGAR_GEFFM_GROUP(true, 0, LGAR_GEFFM_TO_SUM)
   LGAR_MEASURE_POINT(GEFFM_REGIONS, it_a >> 1, (it_b - it_a) >> 1, (it_c - it_b) >> 1, (it - it_c) >> 1)
+  }
 #undef LGAR_GEFFM_GROUP
+#undef LGAR_GEFFM_TO_SUM
   const int rem = M - 2 * it;  // interior nodes left over by the groups of four: 0..3 (3 for the reference's 120 intervals)
   if (rem > 0) {             // ... as one more group whose surplus nodes count as zero
     const f32x2 xa = __builtin_elementwise_fma(ja, dxh2, x0h2) + __builtin_elementwise_fma(ja, dxl2, x0l2);
@@ -1028,6 +1068,18 @@ __device__ __attribute__((noinline)) double geff_mixed(const LayerK<double> &l, 
   }
   return geff_mixed_core(l, h_i, h_f, k0, kn_own, ksat1, nint);
 }
+// ... for cooperating lanes (MODE 6: insert_water, the dry-depth evaluation): the same ends, the interior split over the lanes
+__device__ __attribute__((noinline)) double geff_mixed_coop(const LayerK<double> &l, double theta1, double theta2, int nint, double *tab,
+                                                            int lanes, int r) {
+  const double se_i = se_from_theta(l, theta1);
+  const double se_f = se_from_theta(l, theta2);
+  const double tsat = 1.0 - ex2p(l.m * LGAR_LOG2_1EM12);
+  const double ksat1 = tsat * tsat;
+  double h_i, h_f, k0, kn_own;
+  mixed_end(l, se_i, h_i, k0);
+  mixed_end(l, se_f, h_f, kn_own);  // (geff_mixed's wave-wide shortcut for Se_f == 1 returns what mixed_end returns there)
+  return geff_mixed_core<true>(l, h_i, h_f, k0, kn_own, ksat1, nint, tab, lanes, r);
+}
 // K(Se) / Ksat of both ends of a trapezoid (calc_k_from_se, utils.py:134-156, nudge included), the two evaluated in lockstep:
 // each is a chain of two logarithms and two exponentials in which every operation waits for the one before it.
 __device__ __forceinline__ void mixed_k_pair(const LayerK<double> &l, double se_a, double se_b, double &kr_a, double &kr_b) {
@@ -1044,8 +1096,9 @@ __device__ __forceinline__ void mixed_k_pair(const LayerK<double> &l, double se_
 // so h(Se(theta)) need not be formed again: it would differ from psi by the rounding of the round trip, ~1e-10 relative, three
 // orders below what the fp32 interior resolves -- and only K_r of the two end nodes is evaluated.  kr_f: K(theta2) / Ksat, which
 // calc_dzdt needs as the front's own conductivity (Layer.py:1212-1216) and would otherwise compute a second time.
+template <bool COOPERATE = false>
 __device__ __forceinline__ double geff_mixed_heads(const LayerK<double> &l, double theta1, double theta2, double psi1, double psi2, int nint,
-                                                   double &kr_f) {
+                                                   double &kr_f, double *tab = nullptr, int lanes = 0, int r = 0) {
   const double se_i = se_from_theta(l, theta1);
   const double se_f = se_from_theta(l, theta2);
   const double tsat = 1.0 - ex2p(l.m * LGAR_LOG2_1EM12);
@@ -1053,7 +1106,7 @@ __device__ __forceinline__ double geff_mixed_heads(const LayerK<double> &l, doub
   double k0, kn_own;
   mixed_k_pair(l, se_i, se_f, k0, kn_own);
   kr_f = kn_own;
-  return geff_mixed_core(l, psi1, psi2, k0, kn_own, ksat1, nint);
+  return geff_mixed_core<COOPERATE>(l, psi1, psi2, k0, kn_own, ksat1, nint, tab, lanes, r);
 }
 // calc_geff with use_closed_form_G (lgar/green_ampt.py:85-98): Brooks-Corey estimate from the van Genuchten parameters
 // (calc_bc_lambda / calc_bc_psib, physics/utils.py:54-64, 84-99).  Operator precedence as written in the reference:
@@ -1121,7 +1174,8 @@ template <typename R> struct Glob {
 // lanes (LGAR_COOP_GROUPS slots: the lanes of a group hold the same column, read the same address -- an LDS broadcast -- and
 // write the same value to it), which is what lets a 32-front table of such a wave fit four waves per CU.
 #define LGAR_COOP_GROUPS 16
-constexpr bool coop_mode(int mode) { return mode == 4; }
+constexpr bool coop_mode(int mode) { return mode == 4 || mode == 6; }
+constexpr bool mixed_mode(int mode) { return mode == 3 || mode == 6; }  // (MODE 6: the mixed-precision trapezoid AND cooperating lanes)
 template <typename S, int FMAX, int STRIDE = WAVE> struct FrontsView {
   S *base;             // &lds.f[0][0][slot]
   unsigned char *fl;   // &lds.fl[0][slot]
@@ -1154,7 +1208,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
   // arithmetic policy (see dv / pwx): verification mode in double precision uses the library pow (the reference's
   // torch.pow); the plain-float fast mode divides by reciprocal; everything else is lean pow + IEEE division
   // (3: MODE 3, the mixed-precision kernels -- lean pow with pairwise-combined polynomials, see fast_pow)
-  static constexpr int POL = ((MODE == 0) && (sizeof(R) == 8)) ? 1 : (((MODE != 0) && (sizeof(S) == 4)) ? 2 : ((MODE == 3 && sizeof(S) == 8) ? 3 : 0));
+  static constexpr int POL = ((MODE == 0) && (sizeof(R) == 8)) ? 1 : (((MODE != 0) && (sizeof(S) == 4)) ? 2 : ((mixed_mode(MODE) && sizeof(S) == 8) ? 3 : 0));
   static constexpr int STRIDE = coop_mode(MODE) ? LGAR_COOP_GROUPS : WAVE;  // front-table slots per row (see FrontsView)
   const ColParams<S, NL> &P;
   const LGAR_KARG Glob<R> *G;  // run-time constants, in the kernarg segment (re-pointed by the kernel's time loop)
@@ -1200,10 +1254,13 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
     if constexpr (sizeof(S) != sizeof(R) && sizeof(R) == 8 && MODE != 0) {
       if (share_lanes >= 2 && !G->closed_form) return geff_fused<S>(lk, theta1, theta2, G->nint, xchg, share_lanes);
     }
-    if constexpr (coop_mode(MODE) && sizeof(S) == 8 && sizeof(R) == 8) {  // plain double: cooperating lanes (small jobs)
+    if constexpr (coop_mode(MODE) && !mixed_mode(MODE) && sizeof(S) == 8 && sizeof(R) == 8) {  // plain double: cooperating lanes (small jobs)
       if (share_lanes > 1 && !G->closed_form) return geff_fused<S>(lk, theta1, theta2, G->nint, xchg, share_lanes, coop_rank, riders);
     }
-    if constexpr (MODE == 3 && sizeof(S) == 8 && sizeof(R) == 8) {  // plain double, LgarDims.geff_mode = 1
+    if constexpr (MODE == 6 && sizeof(S) == 8 && sizeof(R) == 8) {  // mixed-precision trapezoid, its groups of nodes split over the lanes
+      if (share_lanes > 1 && !G->closed_form) return geff_mixed_coop(lk, theta1, theta2, G->nint, xchg, share_lanes, coop_rank);
+    }
+    if constexpr (mixed_mode(MODE) && sizeof(S) == 8 && sizeof(R) == 8) {  // plain double, LgarDims.geff_mode = 1
       if (!G->closed_form) return geff_mixed(lk, theta1, theta2, G->nint);
     }
     return G->closed_form ? geff_closed<S, POL>(lk, theta1, theta2) : geff(lk, theta1, theta2, G->nint);
@@ -1214,6 +1271,9 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
                                                            double psi2, double &kr_end) {
     LGAR_MEASURE_POINT(NOGEFF_FRONTS, lk, theta1, theta2, kr_end)
     LGAR_COUNT_GEFF_CALL(1)
+    if constexpr (MODE == 6) {
+      if (share_lanes > 1) return geff_mixed_heads<true>(lk, theta1, theta2, psi1, psi2, G->nint, kr_end, xchg, share_lanes, coop_rank);
+    }
     return geff_mixed_heads(lk, theta1, theta2, psi1, psi2, G->nint, kr_end);
   }
   __device__ __forceinline__ S cum_prev(int k) const {  // cum[k-1], 0 for k == 0
@@ -2066,7 +2126,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
 
   __device__ __forceinline__ void calc_dzdt(S h_p) {
     int i = -1;
-    if constexpr (COOP) {
+    if constexpr (COOP && !mixed_mode(MODE)) {
       // (a group of 8 or more lanes owns TWO rows of the exchange table: lgar_kernels_nl.hip)
       if (share_lanes >= LGAR_COOP_PAIR_LANES && !G->closed_form) i = calc_dzdt_pairs(h_p);
     }
@@ -2089,7 +2149,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
         S delta_theta = F.TH(i) - F.TH(i + 1);
         S g, ki;
         bool fronts_done = false;
-        if constexpr (MODE == 3 && sizeof(S) == 8 && sizeof(R) == 8) {
+        if constexpr (mixed_mode(MODE) && sizeof(S) == 8 && sizeof(R) == 8) {
           if (!G->closed_form) {  // mixed precision: heads from the fronts' psi, K(theta_i) from the trapezoid's wet end node
             double kr_end;
             g = capillary_drive_fronts(lk, theta_1, theta_2, F.PS(i + 1), F.PS(i), kr_end);
@@ -2099,7 +2159,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
           }
         }
         CoopRiders riders;  // (cooperating lanes only)
-        if constexpr (COOP) {
+        if constexpr (COOP && !mixed_mode(MODE)) {
           // cooperating lanes: the front's own K(theta) and the K of the layers above at its psi (two pows each, after the
           // two of theta(psi)) ride along with the four evaluations that open the trapezoid -- see CoopRiders
           if (!G->closed_form && share_lanes >= 5 + k) {
@@ -2144,7 +2204,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
               const LayerK<S> lj = pick_static(P, j);
               S kl;
               bool rode = false;
-              if constexpr (COOP) {
+              if constexpr (COOP && !mixed_mode(MODE)) {
                 if (riders.n > 0) { kl = riders.k[1 + j]; rode = true; }
               }
               if (!rode) {

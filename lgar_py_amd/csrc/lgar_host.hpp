@@ -66,7 +66,7 @@ inline unsigned wave_slots(int waves) {
 // lanes = 1000 waves).  At most 16 columns per wavefront (that many LDS tables): 4..64 lanes; always 1 for fp32, closed-form
 // G, the literal mode, the mixed-precision trapezoid and more than 128 trapezoid intervals.
 template <typename R> inline int cooperating_lanes(const LgarDims *dims, unsigned simds) {
-  if (sizeof(R) != 8 || dims->search_mode == 0 || dims->use_closed_form_G || dims->geff_mode != 0) return 1;
+  if (sizeof(R) != 8 || dims->search_mode == 0 || dims->use_closed_form_G) return 1;
   if (dims->nint > LGAR_COOP_TAB) return 1;  // the groups' LDS tables hold one head / node per trapezoid interval
   if (dims->forward_lanes > 0) return dims->forward_lanes;
   if (dims->search_mode == 2) return 1;      // the capacity chain was asked for (tests): plain kernels

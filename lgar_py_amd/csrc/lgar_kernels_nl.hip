@@ -158,6 +158,10 @@ template <typename R, int NL, int CAP>
 static void launch_fast_kernel(KArgs<R> &a, unsigned nblocks, unsigned *ticket, hipStream_t st, bool mixed) {
   if constexpr (sizeof(R) == 8) {
     if (mixed) {
+      if (a.coop > 1) {  // cooperating lanes with the mixed-precision trapezoid: the 32-front kernel only, as MODE 4
+        if constexpr (CAP == LGAR_FMAX) launch_forward_kernel<R, NL, CAP, 6>(a, nblocks, ticket, st);
+        return;
+      }
       launch_forward_kernel<R, NL, CAP, 3>(a, nblocks, ticket, st);
       return;
     }

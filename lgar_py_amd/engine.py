@@ -39,8 +39,8 @@ class LgarEngine:
     tolerance this reaches against the reference).
     forward_lanes: lanes per column in lgar_forward.  0 (default) = the library gives fp64 trapezoid jobs under one wave per
     SIMD 4..64 cooperating lanes per column (same results bit for bit); 1 = never; 4..64 = exactly that many (a group needs
-    four lanes for the trapezoid's end points, so 2 and 3 do not exist).  Honoured by the fp64 fast modes with the native
-    trapezoid and nint <= 128 only; an explicit request that cannot be honoured raises.
+    four lanes for the trapezoid's end points, so 2 and 3 do not exist).  Honoured by the fp64 fast modes (native or
+    mixed-precision trapezoid) with nint <= 128 only; an explicit request that cannot be honoured raises.
     basin_scratch_bytes: most series memory the engine may allocate on its own behind basin sums whose series the caller
     did not ask for (see forward); 0 = never, such sums are taken by the in-kernel atomics instead.
     bottom_mode: 0 (default) = like the reference, a front reaching the domain bottom faults the column; 1 = it leaves
@@ -107,10 +107,9 @@ class LgarEngine:
         forward_lanes = int(forward_lanes)
         if forward_lanes not in (0, 1) and not 4 <= forward_lanes <= 64:
             raise LgarError("forward_lanes must be 0 (library's choice), 1, or 4..64 (got %d)" % forward_lanes)
-        if forward_lanes > 1 and (dtype != torch.float64 or int(search_mode) == 0 or geff_precision != "native"
-                                  or use_closed_form_G or int(nint) > 128):
-            raise LgarError("forward_lanes=%d cannot be honoured: cooperating lanes exist for the fp64 fast modes with the "
-                            "native trapezoid (no closed-form G, nint <= 128) only" % forward_lanes)
+        if forward_lanes > 1 and (dtype != torch.float64 or int(search_mode) == 0 or use_closed_form_G or int(nint) > 128):
+            raise LgarError("forward_lanes=%d cannot be honoured: cooperating lanes exist for the fp64 fast modes (native or "
+                            "mixed-precision trapezoid; no closed-form G, nint <= 128) only" % forward_lanes)
         d.forward_lanes = forward_lanes
         self.basin_scratch_bytes = int(basin_scratch_bytes)
         FMAX = int(front_slots) if front_slots else _capi.FMAX

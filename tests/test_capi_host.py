@@ -127,7 +127,7 @@ def test_library_choice_of_cooperating_lanes():
 
     assert [lanes(n) for n in (1, 64, 1024, 1025, 2048, 3000, 10_000, 16_384, 16_385, 1 << 20)] == [64, 64, 64, 32, 32, 21, 6, 4, 1, 1]
     assert lanes(10_000, _capi.F32) == 1                 # fp32: no cooperating kernels
-    assert lanes(100, geff_mode=1) == 1                  # mixed-precision trapezoid
+    assert lanes(100, geff_mode=1) == 64                 # mixed-precision trapezoid: its groups of nodes are split as well
     assert lanes(100, use_closed_form_G=1) == 1          # no trapezoid at all
     assert lanes(100, search_mode=0) == 1                # the literal mode
     assert lanes(100, search_mode=2) == 1                # the capacity chain was asked for

@@ -599,6 +599,30 @@ def test_cooperating_lanes_other_interval_counts(nint, lanes):
             assert torch.equal(getattr(ea, t), getattr(eb, t)), (name, t)
 
 
+@pytest.mark.parametrize("lanes", [4, 6, 21, 64])
+@pytest.mark.parametrize("name", ["phil_hourly_3000", "synth1_phil", "manyfronts_pulse_84", "five_layer_phil_500",
+                                  "two_layer_synth1", "frozen07_phil_hourly_400"])
+def test_cooperating_lanes_with_the_mixed_precision_trapezoid(name, lanes):
+    """geff_precision="f32" on a small job: the lanes of a column split the four-node groups of the mixed-precision trapezoid
+    (and the front sweep's evaluations) between them -- every per-step output, the final front tables and the run totals are
+    those of the mixed-precision mode with one lane per column BIT FOR BIT."""
+    import lgar_py_amd as lg
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    ncol = 5
+    res = {}
+    for k in (1, lanes):
+        eng = _engine(g, ncol, torch.float64, forward_lanes=k, geff_precision="f32")
+        pr, pe = _forcing(g, ncol)
+        out = eng.forward(pr, pe, series=lg.ACC_NAMES, check=False)
+        res[k] = (out, eng)
+    a, ea = res[1]
+    b, eb = res[lanes]
+    for nm in lg.ACC_NAMES:
+        assert torch.equal(a[nm], b[nm]), nm
+    for t in ("depth", "theta", "psi", "k", "dzdt", "flags", "n_fronts", "status", "scalars", "totals"):
+        assert torch.equal(getattr(ea, t), getattr(eb, t)), t
+
+
 def test_cooperating_lanes_on_distinct_columns_and_the_default_choice():
     """200 different columns: the library's own choice (64 lanes for this size) and a forced 7 reproduce one lane per column."""
     import lgar_py_amd as lg
