@@ -569,14 +569,16 @@ def test_cooperating_lanes_reproduce_one_lane_per_column(name, lanes):
     assert torch.equal(ea.totals, eb.totals)
 
 
+@pytest.mark.parametrize("precision", ["native", "f32"])
 @pytest.mark.parametrize("nint", [7, 24, 50, 121, 128])
 @pytest.mark.parametrize("lanes", [4, 9, 12, 16, 33, 64])
-def test_cooperating_lanes_other_interval_counts(nint, lanes):
+def test_cooperating_lanes_other_interval_counts(nint, lanes, precision):
     """The cooperative trapezoid at interval counts other than the bundled 120: heads in batches of 16 (+ a tail), nodes and
     terms in rounds of two or four per lane (ragged last rounds), the sum in batches of 16 + 8 + a tail -- bit for bit one lane
     per column (three-layer and six-layer soil: riders and search evaluations of every layer count; groups of 12 lanes and more
     take two moving fronts at a time, odd group sizes leave the upper half one lane more, and with six layers a half of 6 or 8
-    lanes is too small for the riders of a deep front: the one-front path takes over)."""
+    lanes is too small for the riders of a deep front: the one-front path takes over).  precision "f32": the same for the
+    mixed-precision trapezoid, whose four-node groups (1 .. 31 of them, plus the leftover nodes) are split over the lanes."""
     import lgar_py_amd as lg
     for name in ("synth1_phil", "six_layer_synth1"):
         g = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
@@ -587,7 +589,7 @@ def test_cooperating_lanes_other_interval_counts(nint, lanes):
         gg = G(g)
         res = {}
         for k in (1, lanes):
-            eng = _engine(gg, 3, torch.float64, forward_lanes=k)
+            eng = _engine(gg, 3, torch.float64, forward_lanes=k, geff_precision=precision)
             pr, pe = _forcing(gg, 3)
             out = eng.forward(pr, pe, series=lg.ACC_NAMES, check=False)
             res[k] = (out, eng)
