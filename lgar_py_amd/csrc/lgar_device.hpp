@@ -2124,8 +2124,93 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
     }
   }
 
+  // ... and in the mixed-precision mode (MODE 6): the halves of ANY group (the mixed trapezoid's ends are evaluated by every
+  // lane, nothing rides along) take one moving front each -- its trapezoid (geff_mixed_heads, the half's lanes splitting its
+  // four-node groups through the half's own 32 slots of the group's table row) and the conductivities of the layers above at
+  // its psi -- and exchange Geff, K(theta) / Ksat of the wet end and those conductivities.
+  __device__ __forceinline__ int calc_dzdt_pairs_mixed(S h_p) {
+    const int hl = share_lanes >> 1;
+    const bool upper = coop_rank >= hl;
+    const int r2 = upper ? coop_rank - hl : coop_rank;
+    R *tab2 = xchg + (upper ? 64 : 0);
+    int i = -1;
+    auto next_moving = [&]() {  // the one-front loop's scan: fronts that need no Geff are finished on the way
+      while (++i < nf - 1) {
+        if (F.bottom(i)) { F.DZ(i) = S(R(0.0)); continue; }
+        const bool top = F.layer(i) == 0;
+        if (top && val(F.TH(i + 1)) > val(F.TH(i))) status |= LGAR_ST_THETA_ORDER;  // Layer.py:1206-1208
+        if (val(F.TH(i) - F.TH(i + 1)) > R(0.0)) return i;
+        F.DZ(i) = S(R(0.0));
+      }
+      return -1;
+    };
+    for (;;) {
+      const int ia = next_moving();
+      if (ia < 0) return i;
+      const int ib = next_moving();
+      if (ib < 0) return ia - 1;  // no pair: the one-front loop takes over at front ia
+      const int ka = F.layer(ia), kb = F.layer(ib);
+      const int kmax = (ka > kb) ? ka : kb;
+      const int im = upper ? ib : ia;
+      const int k = upper ? kb : ka;
+      const LayerK<S> lk = pick(P, k);
+      LGAR_COUNT_GEFF_CALL(1)
+      LGAR_COUNT_GEFF_CALL(1)
+      double kr_mine;
+      const S g_mine = geff_mixed_heads<true>(lk, F.TH(im + 1), F.TH(im), F.PS(im + 1), F.PS(im), G->nint, kr_mine, tab2, hl, r2);
+      tab2[0] = g_mine;
+      tab2[1] = kr_mine;
+#pragma unroll
+      for (int j = 0; j < NL - 1; j++)
+        if (j < kmax) {  // (both halves, for the deeper of the two fronts: one instruction stream)
+          const LayerK<S> lj = pick_static(P, j);
+          const S tl = theta_from_h<S, POL>(lj, F.PS(im));
+          tab2[2 + j] = k_from_se<S, POL>(lj, se_from_theta(lj, tl));
+        }
+      lds_exchange_point();
+      S g2[2];
+      R kr2[2], kk[2][NL];
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        g2[h] = xchg[h * 64];
+        kr2[h] = xchg[h * 64 + 1];
+#pragma unroll
+        for (int j = 0; j < NL - 1; j++) kk[h][j] = xchg[h * 64 + 2 + j];
+      }
+      lds_exchange_point();
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int f = h ? ib : ia;
+        const int kf = h ? kb : ka;
+        const LayerK<S> lf = pick(P, kf);
+        const S g = g2[h];
+        S ki = lf.ksat * kr2[h];
+        if (f == 0 && new_front_frozen) ki = ki * G->frozen;
+        if (is_nan(val(g))) status |= LGAR_ST_NAN;
+        const S delta_theta = F.TH(f) - F.TH(f + 1);
+        S dzdt;
+        if (kf == 0) {
+          dzdt = dv<POL>(S(R(1.0)), delta_theta) * (dv<POL>(lf.ksat * (g + h_p), F.Z(f)) + ki);
+        } else {
+          S den = S(R(0.0)) + dv<POL>(F.Z(f) - cum_prev(kf), ki);
+#pragma unroll
+          for (int j = 0; j < NL - 1; j++)
+            if (j < kf) {
+              S pt = (j != 0) ? P.cum[(j > 0) ? j - 1 : 0] : S(R(0.0));
+              den = den + dv<POL>(P.cum[j] - pt, S(kk[h][j]));
+            }
+          dzdt = dv<POL>(S(R(1.0)), delta_theta) * (dv<POL>(F.Z(f), den) + dv<POL>(lf.ksat * (g + h_p), F.Z(f)));
+        }
+        F.DZ(f) = dzdt;
+      }
+    }
+  }
+
   __device__ __forceinline__ void calc_dzdt(S h_p) {
     int i = -1;
+    if constexpr (MODE == 6 && sizeof(S) == 8 && sizeof(R) == 8) {
+      if (share_lanes >= 4 && !G->closed_form) i = calc_dzdt_pairs_mixed(h_p);
+    }
     if constexpr (COOP && !mixed_mode(MODE)) {
       // (a group of 8 or more lanes owns TWO rows of the exchange table: lgar_kernels_nl.hip)
       if (share_lanes >= LGAR_COOP_PAIR_LANES && !G->closed_form) i = calc_dzdt_pairs(h_p);
