@@ -551,6 +551,12 @@ __device__ __forceinline__ S geff_fused(const LayerK<S> &l, S theta1, S theta2, 
     k1 = k_from_se(l, se_i);
     LGAR_MEASURE_POINT(CLK, 26)
   }
+  // lg2p / ex2p take finite positive arguments (the exponent of 2^x goes through a float -> int conversion, undefined for
+  // NaN): an end point outside the domain (Se > 1 -> negative pow base -> NaN head; the reference raises ValueError there,
+  // physics/utils.py:25-27) is replaced by a harmless one for the nodes and put back into the result below
+  const S h_i_own = h_i, h_f_own = h_f;
+  const bool outside = is_nan(val(h_i)) || is_nan(val(h_f));
+  if (outside) { h_i = S(R(1.0)); h_f = S(R(1.0)); }
   const S dh = (h_f - h_i) / R(nint);
   const S hdh = dh / R(2.0);
   const S half_m = R(-0.5) * l.m;
@@ -621,12 +627,10 @@ __device__ __forceinline__ S geff_fused(const LayerK<S> &l, S theta1, S theta2, 
     k1 = k2;
     if (sizeof(R) != 4) h2 = h2 + dh;
   }
-  // lg2p / ex2p do not carry NaN: an end point outside the domain (Se > 1 -> negative pow base -> NaN head; the
-  // reference raises ValueError there, physics/utils.py:25-27) must still surface as NaN for the status word
-  const bool outside = is_nan(val(h_i)) || is_nan(val(h_f));
+  // (an end point outside the domain must still surface as NaN for the status word)
   const S res = ab(g / l.ksat);
   LGAR_MEASURE_POINT(CLK, 29)
-  return outside ? res + (h_i + h_f) : res;
+  return outside ? res + (h_i_own + h_f_own) : res;
 }
 // fp32 Geff, lean form (what bench.py measures).  Per node, with x = alpha h and K_r = K / Ksat (Ksat cancels in
 // G = |integral of K dh| / Ksat):
@@ -807,7 +811,10 @@ __device__ __forceinline__ double geff_mixed_core(const LayerK<double> &l, doubl
   const float hm = (float)hmd, hm_lo = (float)(hmd - (double)hm);
   const int M = nint - 1;  // interior nodes j = 1 .. nint-1
   const int pairs = M >> 1;
-  const double jf = (x0 - xcut) / -dx - 1.5;
+  // (node counts from abscissae: one reciprocal of -dx serves the three of them; each count keeps a node or more of margin, and
+  // which loop evaluates a node never changes its value)
+  const double inv_ndx = 1.0 / -dx;
+  const double jf = (x0 - xcut) * inv_ndx - 1.5;
   int safe = (jf > 0.0) ? ((jf < double(M)) ? int(jf) : M) : 0;  // NaN (dx == 0, or a head outside the domain) -> 0
   safe >>= 1;
   int safe_pairs = pairs;
@@ -991,10 +998,10 @@ __device__ __forceinline__ double geff_mixed_core(const LayerK<double> &l, doubl
   }
   if (!COOPERATE && dx < 0.0) {
     const float x_thr = pw(pw(8.0f / 7.0f, (float)l.inv_m) - 1.0f, -(float)l.inv_n);
-    const double js_f = (x0 - (double)(x_thr * 1.0001f)) / -dx - 1.0;  // nodes 1 .. js: x_j > x_thr (1 + 1e-4)
+    const double js_f = (x0 - (double)(x_thr * 1.0001f)) * inv_ndx - 1.0;  // nodes 1 .. js: x_j > x_thr (1 + 1e-4)
     const int js = (js_f > 0.0) ? ((js_f < double(M)) ? int(js_f) : M) : 0;
     ser_pairs = js >> 1;                                               // pairs 0 .. ser_pairs - 1 hold only such nodes
-    const double jd_f = (x0 - (double)(x_thr * 0.9999f)) / -dx + 2.0;  // nodes jd ..: x_j < x_thr (1 - 1e-4)
+    const double jd_f = (x0 - (double)(x_thr * 0.9999f)) * inv_ndx + 2.0;  // nodes jd ..: x_j < x_thr (1 - 1e-4)
     const int jd = !(jd_f < double(M + 2)) ? M + 2 : ((jd_f > 0.0) ? int(jd_f) : 0);
     dir_pair = jd >> 1;                                                // pairs from dir_pair on hold only such nodes
   }
@@ -1013,6 +1020,7 @@ __device__ __forceinline__ double geff_mixed_core(const LayerK<double> &l, doubl
     const int cand = dir_all + bit;
     if (any_lane(dir_pair >= cand) != 0ull) dir_all = cand;
   }
+  LGAR_MEASURE_POINT(CLK, 13)
   for (; it + 1 < ser_all; it += 2, ja = ja + four2, jb = jb + four2) LGAR_GEFFM_GROUP(false, 1, LGAR_GEFFM_TO_SUM)
   const int it_a = it;
   for (; it + 1 < safe_pairs && it < dir_all; it += 2, ja = ja + four2, jb = jb + four2) LGAR_GEFFM_GROUP(false, 0, LGAR_GEFFM_TO_SUM)
@@ -1021,6 +1029,7 @@ __device__ __forceinline__ double geff_mixed_core(const LayerK<double> &l, doubl
   const int it_c = it;
   for (; it + 1 < pairs; it += 2, ja = ja + four2, jb = jb + four2) LGAR_GEFFM_GROUP(true, 0, LGAR_GEFFM_TO_SUM)
   LGAR_MEASURE_POINT(GEFFM_REGIONS, it_a >> 1, (it_b - it_a) >> 1, (it_c - it_b) >> 1, (it - it_c) >> 1)
+  LGAR_MEASURE_POINT(CLK, 14)
   }
 #undef LGAR_GEFFM_GROUP
 #undef LGAR_GEFFM_TO_SUM
@@ -1046,6 +1055,7 @@ __device__ __forceinline__ double geff_mixed_core(const LayerK<double> &l, doubl
   const double kn = (fabs(h_f) < 0.1 || h_f < 0.0) ? ksat1 : kn_own;
   const double res = fabs((0.5 * dh) * ((k0 + kn) + 2.0 * sum));
   const bool outside = is_nan(h_i) || is_nan(h_f);
+  LGAR_MEASURE_POINT(CLK, 16)
   return outside ? res + (h_i + h_f) : res;
 }
 // calc_geff(theta1 -> theta2) in the mixed-precision mode: heads and end nodes from the two water contents (mixed_end).
@@ -1104,7 +1114,9 @@ __device__ __forceinline__ double geff_mixed_heads(const LayerK<double> &l, doub
   const double tsat = 1.0 - ex2p(l.m * LGAR_LOG2_1EM12);
   const double ksat1 = tsat * tsat;
   double k0, kn_own;
+  LGAR_MEASURE_POINT(CLK, 11)
   mixed_k_pair(l, se_i, se_f, k0, kn_own);
+  LGAR_MEASURE_POINT(CLK, 12)
   kr_f = kn_own;
   return geff_mixed_core<COOPERATE>(l, psi1, psi2, k0, kn_own, ksat1, nint, tab, lanes, r);
 }
@@ -1227,6 +1239,14 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
   S memo_theta, memo_g;
   int memo_layer = -1;
   unsigned near_sat_fronts = 0u;  // fronts whose psi the fast modes must send through the reference's theta -> psi round trip
+  // fast modes, one lane per column: the column mass as of the end of move_wetting_front (mass_and_events), still the ending
+  // volume of the sub-step when no pass fired and no front was created after it.  (Cooperating lanes keep the separate walks:
+  // their column mass sums a register copy of the table, and the event scan added to it costs a lone wave more in selects than
+  // the scan's own walk -- configs[1] 78.4 -> 81.8 ms, one column 43.3 -> 45.9 ms, measured.)
+  static constexpr bool FUSED_WALK = (MODE != 0) && !coop_mode(MODE);
+  S post_mass;
+  bool post_mass_valid = false;
+  bool post_event = false;
   S aet_psi_wp_memo;          // calc_aet's half-uptake head of this column (a function of the top layer's parameters only)
   bool aet_psi_wp_known = false;
   bool count_geff = false;              // measurement: count wave-level Geff evaluations in the unused upper bits of `status`
@@ -1368,6 +1388,43 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
     return tot;
   }
 
+  // Layer.mass_balance AND the triggers of the post-sweep passes (front_event_pending) in ONE walk over the front table: both
+  // read every front's depth, theta and tag, and between the sweep and the end of a sub-step nothing else changes them unless a
+  // pass fires or a surficial front is created -- so the fast modes walk the table once per sub-step instead of three times
+  // (column-mass check, event scan, ending volume).  The mass is mass_balance()'s, term by term in the same order.
+  __device__ __forceinline__ S mass_and_events(bool &ev) const {
+    S ls[NL];
+    bool e = false;
+    int i = 0;
+#pragma unroll
+    for (int j = 0; j < NL; j++) {
+      S base = (j == 0) ? S(R(0.0)) : P.cum[j] - P.thick[j];
+      S sum = S(R(0.0));
+      while (i < nf && F.layer(i) == j) {
+        const bool has_next = i + 1 < nf;
+        const int fn = has_next ? F.flag(i + 1) : 0;
+        const bool next_same = has_next && ((fn & 0x7f) == j);
+        const S zi = F.Z(i), ti = F.TH(i);
+        if (has_next) {
+          const S zn = F.Z(i + 1), tn = F.TH(i + 1);
+          e = e || (next_same && !(fn & LGAR_FLAG_BOTTOM) && val(zi) > val(zn));
+          e = e || (next_same && val(ti) <= val(tn));
+          e = e || (val(zi) > val(P.cum[j]));
+          sum = sum + (zi - base) * (next_same ? (ti - tn) : ti);
+        } else {
+          sum = sum + (zi - base) * ti;
+        }
+        i++;
+      }
+      ls[j] = sum;
+    }
+    S tot = ls[NL - 1];
+#pragma unroll
+    for (int j = NL - 2; j >= 0; j--) tot = ls[j] + tot;
+    ev = e;
+    return tot;
+  }
+
   // calc_wetting_front_free_drainage, Layer.py:134-162: argmin psi, ties (and isclose) go deeper
   __device__ __forceinline__ int free_drainage_front() const {
     R psi = val(F.PS(0));
@@ -1391,74 +1448,53 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
     dth = (psi > R(0.0)) ? dv<POL>(-(span * m * n * ap), psi * one_ap) : R(0.0);
   }
 
+  // ... and the second derivative (the double-precision searches fit a power law through value, slope and curvature):
+  // theta'' = theta' ((n - 1) - n (a psi)^n) / (psi (1 + (a psi)^n)).  theta is theta_from_h's operation by operation.
+  __device__ __forceinline__ static void theta_slope2(R alpha, R n, R m, R te, R tr, R psi, R &th, R &dth, R &d2th) {
+    R ap = pwp<POL>(alpha * psi, n);
+    R one_ap = R(1.0) + ap;
+    R op = pwp<POL>(one_ap, m);
+    R span = dv<POL>(R(1.0), op) * (te - tr);
+    th = span + tr;
+    const R r = (psi > R(0.0)) ? dv<POL>(R(1.0), psi * one_ap) : R(0.0);
+    dth = -(span * m * n * ap) * r;
+    d2th = dth * ((n - R(1.0)) - n * ap) * r;
+  }
+
   // search_mode 1: the same root -- psi with |sum_j thick_j (theta_j(psi) - dtheta_j) - prior_mass| <= tolerance --
-  // found by a bracketed Newton iteration (5-8 mass evaluations) instead of the reference's fixed-step decimal
-  // search (58-82 on average, Layer.py:275-317).  theta differs from the literal search by <= tolerance / thickness.
+  // found by a bracketed iteration on the mass and its derivatives (3-5 mass evaluations) instead of the reference's
+  // fixed-step decimal search (58-82 on average, Layer.py:275-317).  theta differs from the literal search by
+  // <= tolerance / thickness.
   // Gradient semantics (dual numbers): psi_final = psi_init + constant, as in the reference (Layer.py:277-288).
   // Cooperating lanes (MODE 4: the lanes of a group carry the SAME column): a mass evaluation is K + 1 independent
   // theta(psi) -- two pows each -- so lane r of the group evaluates layer min(r, K) with that layer's parameters as its
   // operands (ONE instruction stream) and the group exchanges the results through its LDS table; the sums are formed from
   // them in the serial order.  Every value goes through exactly the operations of the serial evaluation: bit-identical.
-  // ... and what the group evaluated together BEFORE a search (coop_sweep_thetas): theta and d theta / d psi of the layers
-  // above and of the front's own layer at the front's psi -- the search's first mass evaluation
+  // FirstEval: what the sweep evaluated BEFORE a search (sweep_layer; coop_sweep_thetas for cooperating lanes): theta and its
+  // two derivatives for the layers above and the front's own layer at the front's psi -- the search's first mass evaluation
   struct FirstEval {
     bool have = false;
-    R th[NL], dth[NL], thk, dthk;
+    R M = R(0.0), dM = R(0.0), d2M = R(0.0);  // the mass sum of the search (layers above first, in order, then the own layer)
+    R thk = R(0.0);                           // theta of the front's own layer at its psi
+    __device__ __forceinline__ void add(R thick, R th, R below, R dth, R d2th) {
+      M += thick * (th - below);
+      dM += thick * dth;
+      d2M += thick * d2th;
+    }
   };
 
+  // Single precision keeps the plain bracketed Newton iteration (its pow is three instructions; the kernel is not bound by
+  // this search).
   template <int K>
-  __device__ __forceinline__ S theta_mass_balance_newton(const LayerK<S> &lk, S psi0, S new_mass, S prior_mass,
-                                                         const S (&dth)[NL], const S (&dthick)[NL], S dth_k, S dthick_k,
-                                                         const FirstEval &fe) {
+  __device__ __forceinline__ S theta_mass_balance_newton_f32(const LayerK<S> &lk, S psi0, S new_mass, S prior_mass,
+                                                             const S (&dth)[NL], const S (&dthick)[NL], S dth_k, S dthick_k) {
     const R prior = val(prior_mass);
     R psi = val(psi0);
     R f = val(new_mass) - prior;
     if (ab(f) <= Tol<R>::mass) return theta_from_h<S, POL>(lk, psi0);
     R M = R(0.0), dM = R(0.0);
-    // my share of a mass evaluation (cooperating lanes): layer c_q's parameters
-    R c_al = val(lk.alpha), c_n = val(lk.n), c_m = val(lk.m), c_te = val(lk.te), c_tr = val(lk.tr);
-    int c_q = K;
-    bool together = false;
-    R last_x = R(-1.0), last_th = R(0.0);  // (cooperating lanes) the own layer's theta of the latest mass evaluation, and its psi
-    if constexpr (COOP && K > 0) {
-      together = share_lanes > K;
-      c_q = coop_rank < K ? coop_rank : K;
-#pragma unroll
-      for (int j = 0; j < K; j++) {
-        const bool mine = c_q == j;
-        c_al = choose(mine, val(P.alpha[j]), c_al); c_n = choose(mine, val(P.n[j]), c_n); c_m = choose(mine, val(P.m[j]), c_m);
-        c_te = choose(mine, val(P.te[j]), c_te); c_tr = choose(mine, val(P.tr[j]), c_tr);
-      }
-    }
-    auto sums = [&](R thk, R dthk, const R (&tj)[NL], const R (&dj)[NL]) {
-      M = val(dthick_k) * (thk - val(dth_k));
-      dM = val(dthick_k) * dthk;
-#pragma unroll
-      for (int j = 0; j < K; j++) {
-        M += val(dthick[j]) * (tj[j] - val(dth[j]));
-        dM += val(dthick[j]) * dj[j];
-      }
-    };
     auto eval = [&](R x) {
       R thk, dthk;
-      if constexpr (COOP && K > 0) {
-        if (together) {
-          R th, dt, tj[NL], dj[NL];
-          theta_slope(c_al, c_n, c_m, c_te, c_tr, x, th, dt);
-          xchg[2 * c_q] = th;  // (lanes with the same c_q store the same value to the same address)
-          xchg[2 * c_q + 1] = dt;
-          lds_exchange_point();
-          thk = xchg[2 * K];
-          dthk = xchg[2 * K + 1];
-#pragma unroll
-          for (int j = 0; j < K; j++) { tj[j] = xchg[2 * j]; dj[j] = xchg[2 * j + 1]; }
-          lds_exchange_point();
-          sums(thk, dthk, tj, dj);
-          last_x = x;
-          last_th = thk;
-          return;
-        }
-      }
       theta_slope(val(lk.alpha), val(lk.n), val(lk.m), val(lk.te), val(lk.tr), x, thk, dthk);
       M = val(dthick_k) * (thk - val(dth_k));
       dM = val(dthick_k) * dthk;
@@ -1472,13 +1508,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
     };
     R lo = R(0.0), hi = R(-1.0);  // bracket f(lo) > 0 > f(hi); hi < 0: not found yet
     bool lo_ok = false;
-    if (fe.have) {  // (cooperating lanes: evaluated with the sweep's own thetas)
-      sums(fe.thk, fe.dthk, fe.th, fe.dth);
-      last_x = psi;
-      last_th = fe.thk;
-    } else {
-      eval(psi);
-    }
+    eval(psi);
     f = M - prior;
     for (int it = 0; it < 64; it++) {
       if (ab(f) <= Tol<R>::mass) break;
@@ -1506,12 +1536,163 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
       if (it == 63) status |= LGAR_ST_ITERCAP;
     }
     const S psi_final = psi0 + (psi - val(psi0));
-    if constexpr (COOP && K > 0) {
-      // theta(psi_final) was part of the last mass evaluation whenever psi0 + (psi - psi0) is psi bit for bit (the difference
-      // is exact for psi within a factor of two of psi0): theta_slope's theta is theta_from_h's, operation by operation
-      if (val(psi_final) == last_x) return S(last_th);
-    }
     return theta_from_h<S, POL>(lk, psi_final);
+  }
+
+  // Double precision (plain and dual numbers): the column mass M(psi) is, layer by layer, close to a shifted power law of psi
+  // -- theta - theta_e ~ -(alpha psi)^n towards saturation, theta - theta_r ~ (alpha psi)^(1-n) in dry soil -- so every step
+  // fits M ~ A - C psi^p through the value, slope and curvature of the present iterate (p = 1 + psi M''/M') and solves that
+  // model for the target: psi_next = psi (1 - p f / (psi M'))^(1/p).  Third order like Halley's method, exact for a power law:
+  // 3 mass evaluations where Newton took 4-5 (f: 1e-2 -> 1e-6 -> 1e-16), and 4-5 where Newton, started from a front that had
+  // just crossed a layer boundary all but saturated (psi ~ 1e-8, M' ~ 0), overshot by six decades and bisected its way back
+  // in 12-16 -- a wavefront waits for its slowest lane, so that tail was most of the search's wave-level cost.  The step itself
+  // costs no double-precision pow: a long step (|t| > 1/64, t = f / (psi M')) takes ratio^(1/p) from the hardware's single-
+  // precision log2 / exp2 (an iterate need not be better than the model), a short one its series in t to third order
+  // (psi_next good to ~t^4: the final steps, t ~ 1e-5, lose nothing).  The bracket (lo, hi) and the bisection fallback are
+  // the Newton version's; so are the termination test -- the true mass, in double precision, within the reference's tolerance
+  // of the target -- and the saturated exit.
+  template <int K>
+  __device__ __forceinline__ S theta_mass_balance_newton(const LayerK<S> &lk, S psi0, S new_mass, S prior_mass,
+                                                         const S (&dth)[NL], const S (&dthick)[NL], S dth_k, S dthick_k,
+                                                         const FirstEval &fe) {
+    if constexpr (sizeof(R) == 4) {
+      (void)fe;
+      return theta_mass_balance_newton_f32<K>(lk, psi0, new_mass, prior_mass, dth, dthick, dth_k, dthick_k);
+    } else {
+    const R prior = val(prior_mass);
+    R psi = val(psi0);
+    R f = val(new_mass) - prior;
+    if (ab(f) <= Tol<R>::mass) return theta_from_h<S, POL>(lk, psi0);
+    R M = R(0.0), dM = R(0.0), d2M = R(0.0);
+    // my share of a mass evaluation (cooperating lanes): layer c_q's parameters
+    R c_al = val(lk.alpha), c_n = val(lk.n), c_m = val(lk.m), c_te = val(lk.te), c_tr = val(lk.tr);
+    int c_q = K;
+    bool together = false;
+    R last_x = R(-1.0), last_th = R(0.0);  // the own layer's theta of the latest mass evaluation, and its psi
+    if constexpr (COOP && K > 0) {
+      together = share_lanes > K;
+      c_q = coop_rank < K ? coop_rank : K;
+#pragma unroll
+      for (int j = 0; j < K; j++) {
+        const bool mine = c_q == j;
+        c_al = choose(mine, val(P.alpha[j]), c_al); c_n = choose(mine, val(P.n[j]), c_n); c_m = choose(mine, val(P.m[j]), c_m);
+        c_te = choose(mine, val(P.te[j]), c_te); c_tr = choose(mine, val(P.tr[j]), c_tr);
+      }
+    }
+    auto sums = [&](R thk, R dthk, R d2thk, const R (&tj)[NL], const R (&dj)[NL], const R (&ej)[NL]) {
+      M = val(dthick_k) * (thk - val(dth_k));
+      dM = val(dthick_k) * dthk;
+      d2M = val(dthick_k) * d2thk;
+#pragma unroll
+      for (int j = 0; j < K; j++) {
+        M += val(dthick[j]) * (tj[j] - val(dth[j]));
+        dM += val(dthick[j]) * dj[j];
+        d2M += val(dthick[j]) * ej[j];
+      }
+    };
+    auto eval = [&](R x) {
+      R thk, dthk, d2thk;
+      if constexpr (COOP && K > 0) {
+        if (together) {
+          R th, dt, d2, tj[NL], dj[NL], ej[NL];
+          theta_slope2(c_al, c_n, c_m, c_te, c_tr, x, th, dt, d2);
+          xchg[3 * c_q] = th;  // (lanes with the same c_q store the same value to the same address)
+          xchg[3 * c_q + 1] = dt;
+          xchg[3 * c_q + 2] = d2;
+          lds_exchange_point();
+          thk = xchg[3 * K];
+          dthk = xchg[3 * K + 1];
+          d2thk = xchg[3 * K + 2];
+#pragma unroll
+          for (int j = 0; j < K; j++) { tj[j] = xchg[3 * j]; dj[j] = xchg[3 * j + 1]; ej[j] = xchg[3 * j + 2]; }
+          lds_exchange_point();
+          sums(thk, dthk, d2thk, tj, dj, ej);
+          last_x = x;
+          last_th = thk;
+          return;
+        }
+      }
+      theta_slope2(val(lk.alpha), val(lk.n), val(lk.m), val(lk.te), val(lk.tr), x, thk, dthk, d2thk);
+      M = val(dthick_k) * (thk - val(dth_k));
+      dM = val(dthick_k) * dthk;
+      d2M = val(dthick_k) * d2thk;
+#pragma unroll
+      for (int j = 0; j < K; j++) {
+        R t1, d1, e1;
+        theta_slope2(val(P.alpha[j]), val(P.n[j]), val(P.m[j]), val(P.te[j]), val(P.tr[j]), x, t1, d1, e1);
+        M += val(dthick[j]) * (t1 - val(dth[j]));
+        dM += val(dthick[j]) * d1;
+        d2M += val(dthick[j]) * e1;
+      }
+      last_x = x;
+      last_th = thk;
+    };
+    R lo = R(0.0), hi = R(-1.0);  // bracket f(lo) > 0 > f(hi); hi < 0: not found yet
+    bool lo_ok = false;
+    if (fe.have) {  // evaluated by the sweep, with its own thetas
+      M = fe.M; dM = fe.dM; d2M = fe.d2M;
+      last_x = psi;
+      last_th = fe.thk;
+    } else {
+      eval(psi);
+    }
+    f = M - prior;
+    const R theta_sat = (val(lk.te) - val(lk.tr)) + val(lk.tr);  // theta_from_h at psi = 0, operation by operation
+    for (int it = 0; it < 64; it++) {
+      if (ab(f) <= Tol<R>::mass) break;
+      if (f > R(0.0)) {
+        lo = psi;
+        lo_ok = true;
+      } else {
+        hi = psi;
+        if (!lo_ok) {
+          // is the target reachable at all?  mass at psi = 0 (saturation) needs no pow
+          R M0 = val(dthick_k) * (theta_sat - val(dth_k));
+#pragma unroll
+          for (int j = 0; j < K; j++) M0 += val(dthick[j]) * (((val(P.te[j]) - val(P.tr[j])) + val(P.tr[j])) - val(dth[j]));
+          if (M0 - prior <= Tol<R>::mass) {  // saturated: the reference walks psi -> 0 (Layer.py:287-316)
+            psi = R(0.0);
+            last_x = R(0.0);
+            last_th = theta_sat;
+            break;
+          }
+          lo_ok = true;
+        }
+      }
+      R pn = R(-1.0);
+      if (dM < R(0.0) && psi > R(0.0)) {
+        const R ipd = dv<POL>(R(1.0), psi * dM);
+        const R t = f * ipd;                                  // the Newton step, relative to psi (negated)
+        const R p = R(1.0) + (psi * psi) * d2M * ipd;         // exponent of the power law through (M, M', M'')
+        const R ratio = R(1.0) - p * t;
+        if (ab(t) <= R(0.015625)) {
+          // psi (ratio^(1/p) - 1) = psi (-t + (1 - p) t^2 / 2 - (2 p - 1)(p - 1) t^3 / 6 + O(t^4))
+          const R c2 = R(0.5) * (R(1.0) - p), c3 = (R(2.0) * p - R(1.0)) * (p - R(1.0)) * R(1.0 / 6.0);
+          pn = psi - (psi * t) * (R(1.0) - t * (c2 - c3 * t));
+        } else if (ratio > R(0.0)) {
+          const float pf = (float)p, tf = (float)t;
+          const float e = (fabsf(pf) > 1e-4f) ? lg2((float)ratio) * rcp32(pf) : -1.44269504f * tf;  // p -> 0: M ~ A - C log psi
+          pn = psi * (R)ex2(e);
+        }
+      }
+      const bool inside = (pn > lo) && (hi < R(0.0) || pn < hi);
+      if (!inside) pn = (hi >= R(0.0)) ? R(0.5) * (lo + hi) : psi * R(2.0) + R(1.0);
+      if (pn == psi) break;  // step below resolution
+      psi = pn;
+      eval(psi);
+      f = M - prior;
+      if (it == 63) status |= LGAR_ST_ITERCAP;
+    }
+    if constexpr (sizeof(S) == sizeof(R)) {
+      // plain reals: theta(psi) was part of the last mass evaluation (theta_slope2's theta is theta_from_h's)
+      if (psi == last_x) return S(last_th);
+      return theta_from_h<S, POL>(lk, S(psi));
+    } else {
+      // dual numbers: psi_final = psi_init + constant, as in the reference's autograd (Layer.py:277-288)
+      const S psi_final = psi0 + (psi - val(psi0));
+      return theta_from_h<S, POL>(lk, psi_final);
+    }
+    }
   }
 
   // theta_mass_balance, Layer.py:242-318 (+ recalculate_mass :211-240).  k = the front's layer;
@@ -1526,7 +1707,12 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
     S psi_prev = psi;  // a tensor in the reference: psi_prev * 0.1 below carries its gradient
     R delta_mass_prev = delta_mass;
     int count_no_change = 0;
-    if (delta_mass <= Tol<R>::mass) return theta_from_h<S, POL>(lk, psi);
+    if (delta_mass <= Tol<R>::mass) {
+      if constexpr (sizeof(S) == sizeof(R)) {
+        if (fe.have) return S(fe.thk);  // theta_from_h(lk, psi), evaluated by the sweep
+      }
+      return theta_from_h<S, POL>(lk, psi);
+    }
     LGAR_MEASURE_POINT(NOSEARCH, lk, psi, new_mass)
     if constexpr (MODE != 0) return theta_mass_balance_newton<K>(lk, psi, new_mass, prior_mass, dth, dthick, dth_k, dthick_k, fe);
     long long it = 0;
@@ -1579,6 +1765,17 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
       bool model = jump;
       const S m0 = current_mass, d0 = depth_new;
       long long it = 0;
+      if constexpr (sizeof(R) == 8) {
+        if (jump && ab(err - Tol<R>::mass) > Tol<R>::mass) {
+          // the mass is linear in this depth: one step to the root (an offset that is a constant w.r.t. the parameters, like the
+          // reference's fixed steps), verified on the true mass; the reference's own loop takes over if its test does not hold
+          depth_new = depth_new + dv<POL>(val(mass_timestep) - val(current_mass), slope);
+          F.Z(fdd) = depth_new;
+          current_mass = mass_balance();
+          err = ab(val(current_mass) - val(mass_timestep));
+          model = false;
+        }
+      }
       while (true) {
         if (!(ab(err - Tol<R>::mass) > Tol<R>::mass)) {
           if (!model) break;
@@ -1641,8 +1838,8 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
   // `share_lanes` items; the serial chain of 2 (7 K + 1) pows becomes one of 2 per round.  theta_slope's theta is
   // theta_from_h's operation by operation.
   template <int K>
-  __device__ __forceinline__ void coop_sweep_thetas(const LayerK<S> &lk, R psi, R psi_below_old, R psi_below, FirstEval &fe,
-                                                    R (&th_below_old)[NL], R (&th_below)[NL]) {
+  __device__ __forceinline__ void coop_sweep_thetas(const LayerK<S> &lk, R psi, R psi_below_old, R psi_below, R (&th)[NL], R (&dt)[NL],
+                                                    R (&d2)[NL], R &thk, R &dthk, R &d2thk, R (&th_below_old)[NL], R (&th_below)[NL]) {
     constexpr int CNT = 3 * K + 1;
     for (int first = 0; first < CNT; first += share_lanes) {
       const int q = first + coop_rank;
@@ -1656,21 +1853,22 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
         x = choose(q == 3 * j + 1, psi_below_old, x);
         x = choose(q == 3 * j + 2, psi_below, x);
       }
-      R th, dt;
-      theta_slope(al, n, m, te, tr, x, th, dt);
-      if (mine) { xchg[2 * q] = th; xchg[2 * q + 1] = dt; }
+      R t0, t1, t2;
+      theta_slope2(al, n, m, te, tr, x, t0, t1, t2);
+      if (mine) { xchg[3 * q] = t0; xchg[3 * q + 1] = t1; xchg[3 * q + 2] = t2; }
     }
     lds_exchange_point();
 #pragma unroll
     for (int j = 0; j < K; j++) {
-      fe.th[j] = xchg[2 * (3 * j)];
-      fe.dth[j] = xchg[2 * (3 * j) + 1];
-      th_below_old[j] = xchg[2 * (3 * j + 1)];
-      th_below[j] = xchg[2 * (3 * j + 2)];
+      th[j] = xchg[3 * (3 * j)];
+      dt[j] = xchg[3 * (3 * j) + 1];
+      d2[j] = xchg[3 * (3 * j) + 2];
+      th_below_old[j] = xchg[3 * (3 * j + 1)];
+      th_below[j] = xchg[3 * (3 * j + 2)];
     }
-    fe.thk = xchg[2 * (3 * K)];
-    fe.dthk = xchg[2 * (3 * K) + 1];
-    fe.have = true;
+    thk = xchg[3 * (3 * K)];
+    dthk = xchg[3 * (3 * K) + 1];
+    d2thk = xchg[3 * (3 * K) + 2];
     lds_exchange_point();
   }
 
@@ -1713,22 +1911,64 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
           S psi = F.PS(i), psi_below = F.PS(i + 1);
           S prior_mass = (oc_z - prev_thick) * (oc_th - c.on_th);
           S new_mass = (z - prev_thick) * (F.TH(i) - F.TH(i + 1));
+          const S t_dth_k = F.TH(i + 1);
+          const S t_dthick_k = z - prev_thick;
           FirstEval fe;
           if constexpr (COOP) {
             if (share_lanes >= 4) {  // cooperating lanes: the thetas below, evaluated by the group together
-              R tbo[NL], tb[NL];
-              coop_sweep_thetas<K>(lk, psi, psi_below_old, psi_below, fe, tbo, tb);
+              R tj[NL], dj[NL], ej[NL], tk, dk, ek, tbo[NL], tb[NL];
+              coop_sweep_thetas<K>(lk, psi, psi_below_old, psi_below, tj, dj, ej, tk, dk, ek, tbo, tb);
 #pragma unroll
               for (int j = 0; j < K; j++) {
                 S lt = P.cum[j] - R(0.0);
-                prior_mass = prior_mass + (lt * (fe.th[j] - tbo[j]));  // (psi_old is psi: the front's own psi has not moved yet)
-                new_mass = new_mass + (lt * (fe.th[j] - tb[j]));
+                prior_mass = prior_mass + (lt * (tj[j] - tbo[j]));  // (psi_old is psi: the front's own psi has not moved yet)
+                new_mass = new_mass + (lt * (tj[j] - tb[j]));
                 dth[j] = tb[j];
                 dthick[j] = lt;
+                fe.add(val(lt), tj[j], tb[j], dj[j], ej[j]);
               }
+              fe.add(val(t_dthick_k), tk, val(t_dth_k), dk, ek);
+              fe.thk = tk;
+              fe.have = true;
             }
           }
-          if (!fe.have) {
+          if constexpr (sizeof(R) == 8) {
+            if (!fe.have) {
+              // The front's own psi has not moved yet (psi_old IS psi: theta of the layers above "before" and "after" are one
+              // evaluation), and the psi of the front below is the same before and after the sweep unless that front moved --
+              // for the active front of a storm it is the layer's untouched boundary front -- so theta_below is evaluated a
+              // second time only when some column of the wavefront needs it.  Plain reals take theta at psi together with its
+              // two derivatives: the search's first mass evaluation (FirstEval).
+              const bool below_moved = any_lane(!same_bits(psi_below_old, psi_below)) != 0ull;
+#pragma unroll
+              for (int j = 0; j < K; j++) {
+                const LayerK<S> lj = pick_static(P, j);
+                const S theta_below_old = theta_from_h<S, POL>(lj, psi_below_old);
+                const S theta_below = below_moved ? theta_from_h<S, POL>(lj, psi_below) : theta_below_old;
+                S lt = P.cum[j] - R(0.0);  // quirk: cumulative thickness (Layer.py:603-604)
+                S theta;
+                if constexpr (sizeof(S) == sizeof(R)) {
+                  R th, dt, d2;
+                  theta_slope2(val(lj.alpha), val(lj.n), val(lj.m), val(lj.te), val(lj.tr), val(psi), th, dt, d2);
+                  fe.add(val(lt), th, val(theta_below), dt, d2);
+                  theta = S(th);
+                } else {
+                  theta = theta_from_h<S, POL>(lj, psi);
+                }
+                prior_mass = prior_mass + (lt * (theta - theta_below_old));
+                new_mass = new_mass + (lt * (theta - theta_below));
+                dth[j] = theta_below;
+                dthick[j] = lt;
+              }
+              if constexpr (sizeof(S) == sizeof(R)) {
+                R tk, dk, ek;
+                theta_slope2(val(lk.alpha), val(lk.n), val(lk.m), val(lk.te), val(lk.tr), val(psi), tk, dk, ek);
+                fe.add(val(t_dthick_k), tk, val(t_dth_k), dk, ek);
+                fe.thk = tk;
+                fe.have = true;
+              }
+            }
+          } else {
 #pragma unroll
             for (int j = 0; j < K; j++) {
               const LayerK<S> lj = pick_static(P, j);
@@ -1743,8 +1983,6 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
               dthick[j] = lt;
             }
           }
-          const S t_dth_k = F.TH(i + 1);
-          const S t_dthick_k = z - prev_thick;
           if (i == c.fdd || feq(c.fdd, i)) prior_mass = prior_mass + c.infiltration - (R(0.0) + c.aet);
           LGAR_MEASURE_POINT(CLK, 22)
           LGAR_MEASURE_POINT(DUP_SEARCH, K, lk, psi, new_mass, prior_mass, dth, dthick, t_dth_k, t_dthick_k)
@@ -1766,17 +2004,41 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
           S base = P.cum[NL - 2];
           S prior_mass = (oc_z - base) * (oc_th - R(0.0));
           S new_mass = (z - base) * (F.TH(i) - R(0.0));
+          FirstEval fe;
 #pragma unroll
           for (int j = 0; j < NL - 1; j++) {
             const LayerK<S> lj = pick_static(P, j);
-            S theta_old = theta_from_h<S, POL>(lj, psi_old);
-            prior_mass = prior_mass + P.thick[j] * (theta_old - R(0.0));
-            S theta = theta_from_h<S, POL>(lj, psi);
-            new_mass = new_mass + P.thick[j] * (theta - R(0.0));
+            if constexpr (sizeof(R) == 8) {
+              // (psi_old IS psi -- the front's psi has not moved yet: one evaluation; plain reals take the derivatives along,
+              // the search's first mass evaluation)
+              S theta;
+              if constexpr (sizeof(S) == sizeof(R)) {
+                R th, dt, d2;
+                theta_slope2(val(lj.alpha), val(lj.n), val(lj.m), val(lj.te), val(lj.tr), val(psi), th, dt, d2);
+                fe.add(val(P.thick[j]), th, R(0.0), dt, d2);
+                theta = S(th);
+              } else {
+                theta = theta_from_h<S, POL>(lj, psi);
+              }
+              prior_mass = prior_mass + P.thick[j] * (theta - R(0.0));
+              new_mass = new_mass + P.thick[j] * (theta - R(0.0));
+            } else {
+              S theta_old = theta_from_h<S, POL>(lj, psi_old);
+              prior_mass = prior_mass + P.thick[j] * (theta_old - R(0.0));
+              S theta = theta_from_h<S, POL>(lj, psi);
+              new_mass = new_mass + P.thick[j] * (theta - R(0.0));
+            }
             dthick[j] = P.thick[j];
           }
+          if constexpr (sizeof(R) == 8 && sizeof(S) == sizeof(R)) {
+            R tk, dk, ek;
+            theta_slope2(val(lk.alpha), val(lk.n), val(lk.m), val(lk.te), val(lk.tr), val(psi), tk, dk, ek);
+            fe.add(val(z) - val(base), tk, R(0.0), dk, ek);
+            fe.thk = tk;
+            fe.have = true;
+          }
           if (F.layer(c.fdd) == NL - 1) prior_mass = prior_mass + c.infiltration - (R(0.0) + c.aet);
-          S theta_new = theta_mass_balance<NL - 1>(lk, psi, new_mass, prior_mass, dth, dthick, S(R(0.0)), z - base);
+          S theta_new = theta_mass_balance<NL - 1>(lk, psi, new_mass, prior_mass, dth, dthick, S(R(0.0)), z - base, fe);
           F.TH(i) = mn(theta_new, lk.te);
           need_psi = true;
         }
@@ -1799,8 +2061,44 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
     c.on_z = c.on_th = c.on_ps = S(R(0.0));
     c.near_sat = 0u;
     sweep_from<NL - 1>(c);
-    check_column_mass(fdd, old_mass, infiltration, aet);  // after front 0 (Layer.py:1296-1305)
     near_sat_fronts = c.near_sat;
+    if constexpr (!FUSED_WALK) {
+      check_column_mass(fdd, old_mass, infiltration, aet);  // after front 0 (Layer.py:1296-1305)
+    } else {
+      // check_column_mass (Layer.py:655-701) in two halves around ONE walk over the front table.  The column mass is LINEAR in
+      // the depth of the (saturated) free-drainage front -- slope = theta_fdd - theta_next, or theta_fdd for the last front of
+      // a layer -- so the reference's fixed-step line search has a closed-form root: one step (an offset that is a constant
+      // w.r.t. the parameters, like the reference's steps), then the walk that every column takes anyway (mass_and_events)
+      // verifies it on the true mass against the reference's own termination test; where that fails -- and for a slope that
+      // is not positive -- the reference's loop runs from where the step landed.
+      const S theta_e_k1 = sel<S, NL>(P.te, F.layer(fdd));
+      const S mass_timestep = (old_mass + infiltration) - (aet + R(0.0));
+      bool stepped = false, literal = false;
+      if (__builtin_expect(ab(val(F.TH(fdd)) - val(theta_e_k1)) < Tol<R>::mass, 0)) {
+        const S current_mass = mass_balance();
+        const R err = ab(val(current_mass) - val(mass_timestep));
+        if (ab(err - Tol<R>::mass) > Tol<R>::mass) {
+          const bool nxt_same = (fdd + 1 < nf) && (F.layer(fdd + 1) == F.layer(fdd));
+          const R slope = nxt_same ? val(F.TH(fdd)) - val(F.TH(fdd + 1)) : val(F.TH(fdd));
+          if (slope > R(0.0)) {
+            F.Z(fdd) = F.Z(fdd) + dv<POL>(val(mass_timestep) - val(current_mass), slope);
+            stepped = true;
+          } else {
+            literal = true;
+          }
+        }
+      }
+      if (__builtin_expect(literal, 0)) check_column_mass(fdd, old_mass, infiltration, aet);
+      post_mass = mass_and_events(post_event);
+      if (stepped) {
+        const R err = ab(val(post_mass) - val(mass_timestep));
+        if (__builtin_expect(ab(err - Tol<R>::mass) > Tol<R>::mass, 0)) {
+          check_column_mass(fdd, old_mass, infiltration, aet);
+          post_mass = mass_and_events(post_event);
+        }
+      }
+      post_mass_valid = true;
+    }
   }
 
   // merge_wetting_fronts / is_passing / pass_front / delete_front, Layer.py:826-892: per layer, the first
@@ -1981,7 +2279,11 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
     S bottom_flux = S(R(0.0));
     // (a per-lane decision: a column's results must not depend on which other columns share its wave)
     LGAR_MEASURE_POINT(DUP_EVENT)
-    if (__builtin_expect(front_event_pending(), 0)) {
+    bool pending;
+    if constexpr (FUSED_WALK) pending = post_event;
+    else pending = front_event_pending();
+    if (__builtin_expect(pending, 0)) {
+      post_mass_valid = false;
       for (int pass = 0; pass < 2; pass++) {
         merge_fronts();
         if (pass == 0) cross_layer_boundary();
@@ -2463,6 +2765,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
     for (int sub = 0; sub < G->nsub; sub++) {
       if (status & (LGAR_ST_BOTTOM | LGAR_ST_OVERFLOW | LGAR_ST_STRUCT)) return;  // dead column
       new_front_frozen = false;
+      post_mass_valid = false;
       S precip_sub = precip * dt;
       S pet_sub = pet * dt;
       S ponded_depth_sub = precip_sub + ponded_water;
@@ -2504,6 +2807,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
         S dry_depth = calc_dry_depth();
         create_surficial_front(dry_depth, ponded_depth_sub, infiltration_sub);
         a_infil = a_infil + infiltration_sub;
+        post_mass_valid = false;
       }
       if (!inserting) {
         // update_ponded_depth, models/dpLGAR.py:369-382
@@ -2523,22 +2827,30 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
       LGAR_MEASURE_POINT(CLK, 6)
       LGAR_MEASURE_POINT(DUP_DZDT, ponded_depth_sub)
       LGAR_MEASURE_POINT(DUP_MB, ending_volume_sub)
-      ending_volume_sub = mass_balance();
+      if constexpr (FUSED_WALK) {
+        // (calc_dzdt touches neither depth nor theta: the walk after the sweep is still the column's mass)
+        if (__builtin_expect(!post_mass_valid, 0)) post_mass = mass_balance();
+        ending_volume_sub = post_mass;
+      } else {
+        ending_volume_sub = mass_balance();
+      }
       LGAR_MEASURE_POINT(CLK, 7)
       previous_precip = precip_sub;
       ending_volume = ending_volume_sub;
       a_aet = a_aet + AET_sub;
       ponded_water = ponded_water_sub;
       // GIUH, models/dpLGAR.py:292-298 and lgar/giuh.py:8-20
+      // (queue entries from the ng-th on are zero and stay zero -- nothing is ever added to them and zeros shift in from above --
+      // so the sum and the shift need no test against ng: the same values, eight adds and eight moves)
       R qsum = R(0.0);
 #pragma unroll
-      for (int i = 0; i < LGAR_GMAX; i++) if (i < G->ng) qsum += val(giuh_q[i]);
+      for (int i = 0; i < LGAR_GMAX; i++) qsum += val(giuh_q[i]);
       if (qsum > R(0.0) || val(runoff_sub) > R(0.0)) {
 #pragma unroll
         for (int i = 0; i < LGAR_GMAX; i++) if (i < G->ng) giuh_q[i] = giuh_q[i] + (G->giuh[i] * runoff_sub);
         S now = giuh_q[0];
 #pragma unroll
-        for (int i = 0; i < LGAR_GMAX - 1; i++) giuh_q[i] = (i < G->ng - 1) ? giuh_q[i + 1] : S(R(0.0));
+        for (int i = 0; i < LGAR_GMAX - 1; i++) giuh_q[i] = giuh_q[i + 1];
         giuh_q[LGAR_GMAX - 1] = S(R(0.0));
         a_giuh = a_giuh + now;
         a_disch = a_disch + now;

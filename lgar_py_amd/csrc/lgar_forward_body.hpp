@@ -251,13 +251,20 @@ __device__ __forceinline__ void forward_lane(const LGAR_KARG KArgs<R> *ap, size_
   // (No software prefetch of the next step's forcing: the two values would have to live in registers across a whole step
   // -- ~10^4 cycles of VALU work -- and at 128 VGPRs they end up as scratch traffic; the load latency of a step's own
   // forcing is covered by the other three waves of the SIMD.)
+  // which per-step series the caller asked for: one word instead of ten pointer tests per step (the pointers themselves are
+  // re-read from the argument block where they are stored through)
+  unsigned series_mask = 0u;
+#pragma unroll
+  for (int j = 0; j < LGAR_NACC; j++)
+    if (a.series[j]) series_mask |= 1u << j;
   const int T = a.T;
   const size_t Nf = (size_t)a.Nf;
   const size_t cf = (Nf == N) ? c : (c / (size_t)a.Fg) % Nf;  // this column's forcing column
   // (MODE 4, one wave per SIMD and registers to spare: the NEXT step's forcing is loaded a step ahead -- a lone wave has nothing
   // else to cover the ~1 us of that load with)
+  constexpr bool AHEAD = coop_mode(MODE);
   R precip_ahead = R(0), pet_ahead = R(0);
-  if constexpr (coop_mode(MODE)) {
+  if constexpr (AHEAD) {
     if (T > 0) {
       precip_ahead = a.precip[cf];
       pet_ahead = a.pet[cf];
@@ -271,7 +278,7 @@ __device__ __forceinline__ void forward_lane(const LGAR_KARG KArgs<R> *ap, size_
     col.G = &ap->G;
     const size_t o = (size_t)t * N + c;
     R precip, pet;
-    if constexpr (coop_mode(MODE)) {
+    if constexpr (AHEAD) {
       precip = precip_ahead;
       pet = pet_ahead;
       const size_t tn = (size_t)((t + 1 < T) ? t + 1 : t);
@@ -281,6 +288,7 @@ __device__ __forceinline__ void forward_lane(const LGAR_KARG KArgs<R> *ap, size_
       precip = a.precip[(size_t)t * Nf + cf];
       pet = a.pet[(size_t)t * Nf + cf];
     }
+    LGAR_MEASURE_POINT(CLK, 9)
     bool active = (t >= t_begin) && (t < t_stop);
     if (active && !a.chain_last && col.nf + a.G.nsub > FMAX) {
       // this step could outgrow the kernel's front capacity: hand the column over, state as of the end of step t-1
@@ -289,7 +297,7 @@ __device__ __forceinline__ void forward_lane(const LGAR_KARG KArgs<R> *ap, size_
     }
     if (any_lane(active) == 0ull) continue;
     if (active) col.forward(precip, pet);
-    if constexpr (coop_mode(MODE)) {
+    if constexpr (AHEAD) {
       // the forcing loaded a step ahead is taken into its registers HERE, before this step's stores are issued: loads and
       // stores share one counter, and a wait for the load placed after the stores would wait for the stores as well
       settle_load(precip_ahead);
@@ -300,8 +308,9 @@ __device__ __forceinline__ void forward_lane(const LGAR_KARG KArgs<R> *ap, size_
     if (active && leader) {
 #pragma unroll
       for (int j = 0; j < LGAR_NACC; j++)
-        if (a.series[j]) a.series[j][o] = acc[j];
+        if (series_mask & (1u << j)) a.series[j][o] = acc[j];
     }
+    LGAR_MEASURE_POINT(CLK, 18)
     if (basin_on) {
       // basin aggregation in the epilogue of the step (physics/MassBalance.py:77-108 over many columns)
       const double w = active ? wgt : 0.0;
@@ -322,6 +331,7 @@ __device__ __forceinline__ void forward_lane(const LGAR_KARG KArgs<R> *ap, size_
       }  // (discharge [7] is the same sum as giuh_runoff [6]: both gain the same routed runoff, models/dpLGAR.py:293-297)
       col.drain();
     }
+    LGAR_MEASURE_POINT(CLK, 21)
   }
   ap = launder(ap);
   const LGAR_KARG KArgs<R> &z = *ap;  // the epilogue re-reads what it needs

@@ -43,10 +43,13 @@ _lib = None
 
 
 def build(force=False):
-    so = os.path.join(_HERE, "liblgar_oracle.so")
+    """liblgar_oracle.so; with LGAR_ORACLE_SANITIZE=1 in the environment the AddressSanitizer + UBSan build instead (the process
+    must then run under LD_PRELOAD of gcc's libasan: tests/test_sanitizers.py)."""
+    san = os.environ.get("LGAR_ORACLE_SANITIZE") == "1"
+    so = os.path.join(_HERE, "liblgar_oracle_asan.so" if san else "liblgar_oracle.so")
     src = os.path.join(_HERE, "lgar_oracle.c")
     if force or not os.path.exists(so) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(so)):
-        subprocess.check_call(["make", "-C", _HERE, "-s"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["asan"] if san else []), stdout=subprocess.DEVNULL)
     return so
 
 

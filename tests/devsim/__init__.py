@@ -53,16 +53,22 @@ def lib(n_layers):
     """libdevsim_<L>.so, built on first use (one soil-layer count per library keeps each build under a minute)."""
     if n_layers in _libs:
         return _libs[n_layers]
-    so = os.path.join(_HERE, "libdevsim_%d.so" % n_layers)
+    # DEVSIM_SANITIZE=1: the AddressSanitizer + UBSan build (the process must run under LD_PRELOAD of clang's asan runtime:
+    # tests/test_sanitizers.py)
+    san = os.environ.get("DEVSIM_SANITIZE") == "1"
+    so = os.path.join(_HERE, "libdevsim_%s%d.so" % ("san_" if san else "", n_layers))
     deps = [os.path.join(_HERE, "devsim.cpp"), os.path.join(ROOT, "include", "lgar.h")] + \
            [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         if not os.path.exists(CLANG):
             raise RuntimeError("clang++ of the ROCm toolchain not found: cannot build the device-code simulator")
-        subprocess.check_call([CLANG, "-x", "c++", "-std=c++17", "-O1", "-ffp-contract=off", "-fPIC", "-shared",
-                               "-I", os.path.join(ROOT, "include"), "-DDEVSIM_LAYERS(X)=X(%d)" % n_layers,
-                               os.path.join(_HERE, "devsim.cpp"), "-o", so + ".tmp"])
-        os.replace(so + ".tmp", so)
+        tmp = "%s.%d.tmp" % (so, os.getpid())  # (several test workers may build the same library at once)
+        # (the sanitizer build at -O0: a minute instead of six at -O1; its fixtures run in a second either way)
+        extra = ["-O0", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-shared-libsan"] if san else []
+        subprocess.check_call([CLANG, "-x", "c++", "-std=c++17", "-O1", "-ffp-contract=off", "-fPIC", "-shared"] + extra +
+                              ["-I", os.path.join(ROOT, "include"), "-DDEVSIM_LAYERS(X)=X(%d)" % n_layers,
+                               os.path.join(_HERE, "devsim.cpp"), "-o", tmp])
+        os.replace(tmp, so)
     L = C.CDLL(so)
     p, i32, vp = C.POINTER, C.c_int32, C.c_void_p
     L.devsim_state_init.argtypes = [p(LgarDims), p(LgarParams), p(LgarState), vp, i32]
@@ -70,6 +76,12 @@ def lib(n_layers):
     L.devsim_tangent.argtypes = [p(LgarDims), p(LgarParams), p(LgarParams), p(LgarForcing), vp, vp, vp, vp, vp, i32]
     _libs[n_layers] = L
     return L
+
+
+def sanitizer_runtime():
+    """clang's AddressSanitizer runtime (what a process loading the DEVSIM_SANITIZE build must LD_PRELOAD)."""
+    out = subprocess.check_output([CLANG, "-print-file-name=libclang_rt.asan-x86_64.so"], text=True).strip()
+    return out if os.path.isabs(out) and os.path.exists(out) else None
 
 
 def prebuild(layers=(2, 3, 4)):

@@ -62,6 +62,46 @@ def test_device_code_fp64_trajectory_vs_reference_golden(name, mode):
         check_fault_kind(g, eng.status)
 
 
+# (search_mode, geff_mode): fast through the capacity chain, literal, mixed precision; bars on depth / theta relative to the
+# reference's own value (observed: 4e-10 fast, 2e-9 literal).  The mixed-precision mode holds 1e-6 except in the step of a front
+# event, where a random 1e-7 difference between consecutive Geff values is amplified ~50x (observed: one
+# step of two_layer_synth1 at 7e-6, 8e-8 elsewhere): every step within 2e-5 -- the mode's bar on per-step fluxes -- and all but
+# 2 % of the steps within 1e-6.
+STEPWISE_MODES = {"fast": (2, 0, 1e-6, 1e-6), "literal": (0, 0, 1e-7, 1e-7), "mixed": (2, 1, 2e-5, 1e-6)}
+
+
+@pytest.mark.parametrize("mode", list(STEPWISE_MODES))
+@pytest.mark.parametrize("name", TRAJ)
+def test_device_code_front_table_at_every_step_vs_reference_golden(name, mode):
+    """north_star: "per-front depth/theta".  The engine is stepped one forcing row at a time and its WHOLE front table --
+    front count, layer tags, to_bottom flags, depth, theta (layers/WettingFront.py:38-49, models/dpLGAR.py:176-298) -- is compared
+    with the reference's at EVERY step, not only at the last one."""
+    sm, gm, bar, usual = STEPWISE_MODES[mode]
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    crash = int(g["crash_step"])
+    T = crash if crash >= 0 else g["forcing"].shape[0]
+    if mode == "literal" and T > 600:
+        T = 600  # (the literal line searches take ~100x the evaluations: the head of the long fixtures)
+    eng = _engine(g, 1, search_mode=sm, geff_mode=gm)
+    f = g["forcing"]
+    frec = g["fronts"].shape[1]
+    above = 0
+    for t in range(T):
+        eng.forward(f[t:t + 1, 0:1], f[t:t + 1, 1:2], series=())
+        nf = int(g["nfronts"][t])
+        assert int(eng.n_fronts[0]) == nf, (t, int(eng.n_fronts[0]), nf)
+        q = min(nf, frec)
+        fl = eng.flags[:q, 0]
+        assert ((fl & 0x7F) == g["front_layer"][t, :q]).all(), t
+        assert ((fl >> 7) == g["front_bottom"][t, :q]).all(), t
+        dz = _rel(eng.depth[:q, 0], g["fronts"][t, :q, 0]).max()
+        dth = _rel(eng.theta[:q, 0], g["fronts"][t, :q, 1]).max()
+        above += int(max(dz, dth) > usual)
+        assert dz <= bar and dth <= bar, (t, dz, dth)
+    assert above <= max(1, T // 50), (above, T)
+    assert int(eng.status[0]) == 0
+
+
 @pytest.mark.parametrize("name", ["synth1_phil", "phil_hourly_3000", "four_layer_synth0_600", "two_layer_phil_600",
                                   "closedG_synth1_phil", "frozen07_phil_hourly_400", "manyfronts_pulse_84", "rand06"])
 def test_device_code_literal_mode_vs_reference_golden(name):

@@ -58,6 +58,43 @@ def test_two_ranks_sharing_one_gpu_equal_single_rank(tmp_path):
 
 
 @pytest.mark.timeout(900)
+def test_two_ranks_shared_parameter_training_equals_single_process(tmp_path):
+    """SURVEY section 8e, "training with shared parameters adds an all-reduce of L x 3 gradient scalars"
+    (agents/DifferentiableLGAR.py:94-172): two ranks share the basin's 96 columns (and the one GPU), exchange the [T] runoff sums
+    and the 9 parameter gradients every epoch, and after two epochs hold bit-equal parameters that equal the single-process
+    run's to 1e-12."""
+    N, epochs = 96, 2
+
+    def launch(world, out):
+        port = _free_port()
+        procs = []
+        for r in range(world):
+            env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                       HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            env.pop("WORLD_SIZE", None)
+            env.pop("RANK", None)
+            if world > 1:
+                env.update(RANK=str(r), WORLD_SIZE=str(world))
+            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_agent_worker.py"), str(tmp_path), out,
+                                           str(N), str(epochs)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+        for p in procs:
+            o, _ = p.communicate(timeout=600)
+            assert p.returncode == 0, o[-3000:]
+
+    launch(1, str(tmp_path / "one_%d.npz"))
+    launch(2, str(tmp_path / "two_%d.npz"))
+    one = np.load(tmp_path / "one_0.npz")
+    parts = [np.load(tmp_path / ("two_%d.npz" % r)) for r in range(2)]
+    assert not bool(one["sharded"]) and all(bool(p["sharded"]) and bool(p["in_sync"]) for p in parts)
+    assert (int(parts[0]["lo"]), int(parts[0]["hi"]), int(parts[1]["lo"]), int(parts[1]["hi"])) == (0, 48, 48, 96)
+    assert np.array_equal(parts[0]["params"].view(np.int64), parts[1]["params"].view(np.int64))
+    for p in parts:
+        assert np.abs(p["params"] - one["params"]).max() <= 1e-12, np.abs(p["params"] - one["params"]).max()
+        assert np.allclose(p["loss"], one["loss"], rtol=1e-12, atol=0)
+    assert np.isfinite(one["loss"]).all() and len(one["loss"]) == epochs
+
+
+@pytest.mark.timeout(900)
 def test_bench_self_spawns_its_ranks():
     """`python bench.py --gpus 2` with no launcher starts two ranks itself (gloo rehearsal on the one GPU) and reports
     n_gpus = 2 with twice the single-rank work; `--gpus 2` can therefore never silently measure one GPU."""

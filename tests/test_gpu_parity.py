@@ -80,6 +80,54 @@ def test_fp64_trajectory_vs_reference_golden(name, mode):
         check_fault_kind(g, eng.status.cpu().numpy())
 
 
+# engine settings per mode and the bar on depth / theta (relative to the reference's own value); "fast" lets the library choose
+# its kernel for a job this small (cooperating lanes), "fast_capacity_chain" forces the one-lane-per-column kernels of the big jobs
+# The mixed-precision mode holds 1e-6 except in the step of a front event, where a random 1e-7 difference between consecutive
+# Geff values is amplified ~50x: every step within 2e-5 -- the mode's bar on per-step fluxes -- and all but
+# 2 % of the steps within 2e-6.
+STEPWISE_MODES = {"fast": (dict(search_mode=1), 1e-6, 1e-6), "fast_capacity_chain": (dict(search_mode=2), 1e-6, 1e-6),
+                  "literal": (dict(search_mode=0), 1e-7, 1e-7), "mixed": (dict(search_mode=2, geff_precision="f32"), 2e-5, 2e-6),
+                  "mixed_cooperating_lanes": (dict(search_mode=1, geff_precision="f32"), 2e-5, 2e-6)}
+
+
+@pytest.mark.parametrize("mode", list(STEPWISE_MODES))
+@pytest.mark.parametrize("name", TRAJ)
+def test_fp64_front_table_at_every_step_vs_reference_golden(name, mode):
+    """north_star: "per-front depth/theta".  The HIP engine is stepped one forcing row at a time through the C-ABI and its WHOLE
+    front table -- front count, layer tags, to_bottom flags, depth, theta (layers/WettingFront.py:38-49,
+    models/dpLGAR.py:176-298) -- is compared with the reference's at EVERY step, not only at the last one."""
+    kw, bar, usual = STEPWISE_MODES[mode]
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    crash = int(g["crash_step"])
+    T = crash if crash >= 0 else g["forcing"].shape[0]
+    if mode == "literal" and T > 600:
+        T = 600  # (the literal line searches take ~100x the evaluations: the head of the long fixtures)
+    ncol = 2
+    eng = _engine(g, ncol, torch.float64, **kw)
+    pr, pe = _forcing(g, ncol, slice(0, T))
+    F = eng.depth.shape[0]
+    dev = eng.depth.device
+    Z = torch.empty(T, F, dtype=torch.float64, device=dev)
+    TH = torch.empty(T, F, dtype=torch.float64, device=dev)
+    FL = torch.empty(T, F, dtype=torch.uint8, device=dev)
+    NF = torch.empty(T, dtype=torch.int32, device=dev)
+    for t in range(T):
+        eng.forward(pr[t:t + 1], pe[t:t + 1], series=(), check=False)
+        Z[t], TH[t], FL[t], NF[t] = eng.depth[:, 0], eng.theta[:, 0], eng.flags[:, 0], eng.n_fronts[0]
+    assert bool((eng.status == 0).all())
+    assert torch.equal(eng.depth[:, 0], eng.depth[:, 1]) and torch.equal(eng.theta[:, 0], eng.theta[:, 1])
+    Z, TH, FL, NF = Z.cpu().numpy(), TH.cpu().numpy(), FL.cpu().numpy(), NF.cpu().numpy()
+    assert (NF == g["nfronts"][:T]).all(), int(np.argmax(NF != g["nfronts"][:T]))
+    frec = min(g["fronts"].shape[1], F)
+    live = np.arange(frec)[None, :] < np.minimum(NF, frec)[:, None]
+    assert ((FL[:, :frec] & 0x7F)[live] == g["front_layer"][:T, :frec][live]).all()
+    assert ((FL[:, :frec] >> 7)[live] == g["front_bottom"][:T, :frec][live]).all()
+    err = np.maximum(_rel(Z[:, :frec], g["fronts"][:T, :frec, 0]), _rel(TH[:, :frec], g["fronts"][:T, :frec, 1]))
+    err = np.where(live, err, 0.0).max(axis=1)  # worst front of every step
+    assert err.max() <= bar, (int(err.argmax()), float(err.max()))
+    assert int((err > usual).sum()) <= max(1, T // 50), (int((err > usual).sum()), T, float(err.max()))
+
+
 def test_config2_10k_replicated_phillipsburg_fp64():
     """BASELINE configs[1]: 10k replicated Phillipsburg columns, fp64, every column == reference to 1e-6 rel."""
     import lgar_py_amd as lg
