@@ -111,10 +111,12 @@ typedef struct {
                                 modes only; ignored elsewhere): mixed precision -- column state, branches and mass bookkeeping
                                 stay fp64, the two heads and the two end nodes of the trapezoid stay fp64, its 119 interior
                                 nodes use the fp32 hardware transcendentals and are summed in fp64 */
-  int32_t forward_lanes;     /* lgar_forward, LGAR_F64 fast modes with the trapezoid (ignored elsewhere).  0: the library decides --
-                                jobs under one wave per SIMD get 4..64 cooperating lanes per column, which split the nodes of
-                                the Geff trapezoid between them (results bit for bit those of one lane per column); 1: one lane
-                                per column whatever the job size; 4 .. 64: that many (64 / lanes columns per wavefront) */
+  int32_t forward_lanes;     /* lgar_forward, LGAR_F64 fast modes with the trapezoid, native (geff_mode 0) or mixed precision
+                                (geff_mode 1) alike (ignored elsewhere).  0: the library decides -- jobs under one wave per SIMD
+                                get 4..64 cooperating lanes per column, which split the nodes of the Geff trapezoid and the
+                                front sweep's independent evaluations between them (results bit for bit those of one lane per
+                                column in the same geff_mode); 1: one lane per column whatever the job size; 4 .. 64: that
+                                many (64 / lanes columns per wavefront) */
   int32_t reserved4;
 } LgarDims;
 

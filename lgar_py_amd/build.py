@@ -120,6 +120,10 @@ def _link(hipcc, objs, out, verbose=False):
 def build_variant(name, extra_flags, verbose=False, layers=(3,), tangent=False):
     """Measurement variants (tools/ablate.py): the same sources with extra -D flags -> csrc/variants/liblgar_hip_<name>.so
     (select one at run time with LGAR_LIB=<path>); forward path of the given layer counts only unless tangent=True."""
+    if len(layers) > 1 and any(f.startswith(("-DLGAR_CLOCKS", "-DLGAR_COUNT_")) for f in extra_flags):
+        # lgar_debug_counters / lgar_debug_clocks (lgar_kernels_nl.hip) are defined -- with their static counter arrays -- once
+        # per layer count's translation unit: two of them would collide at link time or read back the wrong unit's counters
+        raise ValueError("measurement read-backs (LGAR_CLOCKS / LGAR_COUNT_*) exist per layer count: build one layer count")
     vdir = os.path.join(CSRC, "variants")
     out = os.path.join(vdir, "liblgar_hip_%s.so" % name)
     units = [u for u in UNITS if not u[2] or int(u[2][1:]) in layers]

@@ -113,14 +113,19 @@ template <int POL> __device__ __forceinline__ float dv(float a, float b) {
 // POL 0 in double precision (fast modes): a / b as a * (1 / b) from v_rcp_f64, one Newton step on the reciprocal and one
 // correction of the quotient -- six instructions, within an ulp of the IEEE quotient, against the ~14 of the correctly rounded
 // divide (v_div_scale / v_div_fmas / v_div_fixup); a column step takes ~25 of them, each on its wave's critical path.  The
-// divisors of the column physics are finite and non-zero (depths, theta differences that were tested > 0, 1 + (alpha psi)^n).
+// divisors of the column physics are as a rule finite and non-zero (depths, theta differences that were tested > 0,
+// 1 + (alpha psi)^n); where one is not -- b = 0, inf or denormal, a = inf: the Newton steps meet inf * 0 and come out NaN
+// where the quotient is inf, 0 or finite (an overflowed (alpha h)^n in theta_from_h must give theta_r, not NaN) -- the NaN
+// result sends the lanes concerned through the IEEE divide (a compare and a branch that is practically never taken).
 // Se = (theta - theta_r) / (theta_e - theta_r) keeps the IEEE divide (se_from_theta: x / x must be exactly 1).
 #ifndef LGAR_DEVSIM
 __device__ __forceinline__ double lean_div(double a, double b) {
   double r = __builtin_amdgcn_rcp(b);
   r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
   const double q = a * r;
-  return __builtin_fma(__builtin_fma(-b, q, a), r, q);
+  double res = __builtin_fma(__builtin_fma(-b, q, a), r, q);
+  if (__builtin_expect(res != res, 0)) res = a / b;
+  return res;
 }
 #else
 __device__ __forceinline__ double lean_div(double a, double b) { return a / b; }

@@ -182,6 +182,7 @@ __device__ __forceinline__ void forward_lane(const LGAR_KARG KArgs<R> *ap, size_
     if (any_lane(t_begin < a.T) == 0ull) return;  // nothing handed over to this wave
   }
   status &= LGAR_ST_FAULT_MASK;
+  LGAR_MEASURE_POINT(POISON_LDS, lds, coop_mode(MODE) ? group : lane)
   ColParams<R, NL> P;
   load_params<R, NL>(a, c, P);
   // front-table slot: my own, or (MODE 4) my group's -- the lanes of a group hold the same column
@@ -272,6 +273,7 @@ __device__ __forceinline__ void forward_lane(const LGAR_KARG KArgs<R> *ap, size_
     settle_load(precip_ahead);  // (in their registers before the loop: see the loop's own note)
     settle_load(pet_ahead);
   }
+  LGAR_MEASURE_POINT(BALLAST_INIT, a, c)
   for (int t = 0; t < T; t++) {
     ap = launder(ap);
     const LGAR_KARG KArgs<R> &a = *ap;  // (shadows the outer reference on purpose)
@@ -297,6 +299,7 @@ __device__ __forceinline__ void forward_lane(const LGAR_KARG KArgs<R> *ap, size_
     }
     if (any_lane(active) == 0ull) continue;
     if (active) col.forward(precip, pet);
+    LGAR_MEASURE_POINT(BALLAST_TOUCH)
     if constexpr (AHEAD) {
       // the forcing loaded a step ahead is taken into its registers HERE, before this step's stores are issued: loads and
       // stores share one counter, and a wait for the load placed after the stores would wait for the stores as well
@@ -333,6 +336,7 @@ __device__ __forceinline__ void forward_lane(const LGAR_KARG KArgs<R> *ap, size_
     }
     LGAR_MEASURE_POINT(CLK, 21)
   }
+  LGAR_MEASURE_POINT(BALLAST_FOLD, col)
   ap = launder(ap);
   const LGAR_KARG KArgs<R> &z = *ap;  // the epilogue re-reads what it needs
   if (z.counters != nullptr) {

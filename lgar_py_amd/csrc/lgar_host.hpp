@@ -64,7 +64,8 @@ inline unsigned wave_slots(int waves) {
 // (ceil(n_columns / 1024) columns per wavefront, 64 / that lanes each) -- two such waves on a SIMD contend for its vector ALU
 // in the trapezoid and the gain is gone (measured: 10 000 columns x 8 lanes = 1250 waves run slower than 157 plain ones; 6
 // lanes = 1000 waves).  At most 16 columns per wavefront (that many LDS tables): 4..64 lanes; always 1 for fp32, closed-form
-// G, the literal mode, the mixed-precision trapezoid and more than 128 trapezoid intervals.
+// G, the literal mode and more than 128 trapezoid intervals.  The rule is the same for the native double-precision trapezoid
+// (MODE 4 kernels) and the mixed-precision one (LgarDims.geff_mode = 1: MODE 6 kernels).
 template <typename R> inline int cooperating_lanes(const LgarDims *dims, unsigned simds) {
   if (sizeof(R) != 8 || dims->search_mode == 0 || dims->use_closed_form_G) return 1;
   if (dims->nint > LGAR_COOP_TAB) return 1;  // the groups' LDS tables hold one head / node per trapezoid interval

@@ -42,9 +42,11 @@ __global__ __launch_bounds__(WAVE) void lgar_init_kernel(KArgs<R> a) {
   init_lane<R, NL, CAP>((const LGAR_KARG KArgs<R> *)__builtin_amdgcn_kernarg_segment_ptr(), c, lane, lds);
 }
 
-// LDS tables through which cooperating lanes exchange trapezoid heads and nodes (lgar_device.hpp geff_nodes_cooperative): one
-// per group of lanes, MODE 4 kernels only (double precision).  With the front table kept once per group as well, a 32-front
-// wave of such a kernel takes 37 KB: four waves per CU, one per SIMD -- all a cooperating job may have.
+// LDS tables through which cooperating lanes exchange trapezoid heads and nodes (lgar_device.hpp geff_nodes_cooperative,
+// geff_mixed_core<true>), sweep thetas and mass evaluations: one per group of lanes, in the cooperating-lanes kernels only
+// (MODE 4: native double-precision trapezoid, MODE 6: mixed-precision trapezoid).  With the front table kept once per group as
+// well, a 32-front wave of such a kernel takes 34 KB of LDS (front table 17 KB, these tables 16.6 KB, the groups' sums): four
+// waves per CU, one per SIMD -- all a cooperating job may have.
 template <typename R, int MODE> struct CoopLDS {
   static constexpr bool on = (sizeof(R) == 8) && coop_mode(MODE);
   R tab[on ? LGAR_COOP_GROUPS : 1][on ? LGAR_COOP_TAB_ROW : 1];

@@ -164,3 +164,42 @@ static __shared__ unsigned long long lgar_dbg_clk_last;
 #else
 #define LGAR_POINT_CLK(id)
 #endif
+
+// ---- register ballast (-DLGAR_BALLAST=K): K values per lane that live through the whole time loop of a forward kernel and must
+// be in registers once per step -- K more registers for the allocator to spill around the trapezoid.  How
+// tools/spill_determinism.sh studies what spill code does to the results of the 128-register fp32 kernel.
+#ifdef LGAR_BALLAST
+#define LGAR_POINT_BALLAST_INIT(a, c)                                                               \
+  R ballast_[LGAR_BALLAST];                                                                        \
+  _Pragma("unroll") for (int q_ = 0; q_ < LGAR_BALLAST; q_++) ballast_[q_] = a.theta_e[c] * R(q_ + 1);
+#define LGAR_POINT_BALLAST_TOUCH()                                                                  \
+  _Pragma("unroll") for (int q_ = 0; q_ < LGAR_BALLAST; q_++) ballast_[q_] = opaque(ballast_[q_]);
+#define LGAR_POINT_BALLAST_FOLD(col)                                                                \
+  {                                                                                                \
+    R bs_ = R(0);                                                                                  \
+    _Pragma("unroll") for (int q_ = 0; q_ < LGAR_BALLAST; q_++) bs_ += ballast_[q_];                \
+    if (bs_ == R(-12345.0)) col.status |= LGAR_ST_STRUCT; /* never true */                         \
+  }
+#else
+#define LGAR_POINT_BALLAST_INIT(a, c)
+#define LGAR_POINT_BALLAST_TOUCH()
+#define LGAR_POINT_BALLAST_FOLD(col)
+#endif
+
+// ---- LDS poison (-DLGAR_POISON_LDS): before a wave loads a block's state, every row of its front table and of its sums is filled
+// with NaN -- what the block before left there is gone.  A persistent wave integrates whatever blocks the ticket counter hands it,
+// so a kernel that read a row it had not written (a front index at or beyond n_fronts) would give results that depend on the
+// order of the blocks, i.e. differ from run to run; with the poison such a read turns the column's results into NaN.  The
+// product's results must not change (tools/determinism_probe.py prints a digest to compare).
+#ifdef LGAR_POISON_LDS
+#define LGAR_POINT_POISON_LDS(lds, slot)                                                            \
+  {                                                                                                \
+    const R nan_ = R(__builtin_nan(""));                                                           \
+    for (int f_ = 0; f_ < 4; f_++)                                                                 \
+      for (int i_ = 0; i_ < FMAX; i_++) lds.f[f_][i_][slot] = nan_;                                \
+    for (int i_ = 0; i_ < FMAX; i_++) lds.fl[i_][slot] = (unsigned char)0x7f;                      \
+    for (int i_ = 0; i_ < (int)(sizeof(lds.sums) / sizeof(lds.sums[0])); i_++) lds.sums[i_][slot] = nan_; \
+  }
+#else
+#define LGAR_POINT_POISON_LDS(lds, slot)
+#endif

@@ -27,7 +27,7 @@ def main():
     soil = write_soil_dat(os.path.join(d, "soil.dat"))
     forcing = write_forcing(os.path.join(d, "f.csv"), f, step_min=5)
     ov = {"data.forcing_file": forcing, "data.soil_params_file": soil, "models.hyperparameters.epochs": epochs,
-          "models.hyperparameters.learning_rate": 0.02, "models.hyperparameters.warmup": 0, "n_columns": n_columns}
+          "models.hyperparameters.learning_rate": 2e-4, "models.hyperparameters.warmup": 0, "n_columns": n_columns}
     cfg = config.load_config(data="synth_1", models="five_minute", cwd=tmp, overrides=ov)
     scale = 0.5 + np.arange(n_columns) / float(n_columns)  # uneven rainfall over the basin
     agent = DifferentiableLGAR(cfg, observations=0.05 * np.ones(f.shape[0]), log=lambda s: None, forcing_scale=scale)

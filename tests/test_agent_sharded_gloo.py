@@ -32,7 +32,7 @@ def _agent(tmp, world_rank=None):
     soil = write_soil_dat(os.path.join(tmp, tag, "soil.dat"))
     forcing = write_forcing(os.path.join(tmp, tag, "f.csv"), f, step_min=5)
     ov = {"data.forcing_file": forcing, "data.soil_params_file": soil, "models.hyperparameters.epochs": EPOCHS,
-          "models.hyperparameters.learning_rate": 0.02, "models.hyperparameters.warmup": 0, "models.endtime": 8.0,
+          "models.hyperparameters.learning_rate": 2e-4, "models.hyperparameters.warmup": 0, "models.endtime": 8.0,
           "n_columns": N_COLUMNS, "device": "cuda:0"}
     cfg = config.load_config(data="synth_1", models="five_minute", cwd=tmp, overrides=ov)
     scale = 0.6 + 0.2 * np.arange(N_COLUMNS)  # uneven rainfall: the columns differ, and so do the ranks' shares of the gradient
@@ -70,7 +70,7 @@ def test_two_rank_shared_parameter_training_equals_single_process(tmp_path):
     p0 = _params(single).copy()
     single.run()
     p1 = _params(single)
-    assert np.abs(p1 - p0).max() > 1e-3  # the parameters moved
+    assert np.abs(p1 - p0).max() > 1e-4  # the parameters moved (Adam: ~ the learning rate per epoch)
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]

@@ -28,7 +28,9 @@ def test_bench_json_contract():
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
-    assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    # bound names what limits the kernel (vector-ALU issue: VERDICT r04 asked for the honest label); achieved / peak / frac are
+    # the HBM figures of the contract, and the compute side's busy fraction sits beside them at top level
+    assert r["bound"] == "valu-issue" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and "valu_busy_frac" in d
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] == 4 and c["value"] > 0 and "sample" in c

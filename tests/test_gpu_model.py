@@ -199,6 +199,30 @@ def test_streamed_per_column_forcing_from_a_mapped_file_equals_single_shot(tmp_p
     assert torch.equal(got32["runoff"], want["runoff"])
     with pytest.raises(ValueError):
         run_streamed_columns(mk(), pr[:, :5], None)
+    # the three ways a chunk leaves the host give the same bits: pread out of the file (above), numpy copies out of a plain
+    # array, and a map REGISTERED with the runtime (no staging copy); and the per-step series streamed BACK into host files --
+    # one registered (the copy engines write the page cache), one plain (pinned double buffer + writer thread)
+    from lgar_py_amd.pipeline import close_forcing_file, create_forcing_file
+    assert st["source"].startswith("pread")
+    st2 = {}
+    got2 = run_streamed_columns(mk(), np.array(fp), np.array(fe), chunk=97, series=("runoff",), reduce_basin=False, check=False,
+                                stats=st2, reader_threads=3)
+    assert st2["source"].startswith("numpy") and torch.equal(got2["runoff"], full["runoff"])
+    rp, re_ = open_forcing_file(str(tmp_path / "precip.npy"), register=True), open_forcing_file(str(tmp_path / "pet.npy"), register=True)
+    o1 = open_forcing_file(create_forcing_file(str(tmp_path / "runoff_out.npy"), (T, N), "float64"), register=True)
+    o2 = open_forcing_file(create_forcing_file(str(tmp_path / "aet_out.npy"), (T, N), "float64"), writable=True)
+    try:
+        st3 = {}
+        h = mk()
+        basin3 = run_streamed_columns(h, rp, re_, chunk=97, series=("runoff",), check=False, stats=st3,
+                                      host_out={"runoff": o1, "AET": o2})["runoff"]
+        assert st3["source"].startswith("registered") and st3["bytes_device_to_host"] == 2 * T * N * 8
+        assert np.array_equal(np.asarray(o1), full["runoff"].cpu().numpy()) and np.array_equal(np.asarray(o2), full["AET"].cpu().numpy())
+        assert torch.allclose(basin3, full["runoff"].sum(1), rtol=1e-12, atol=1e-12) and torch.equal(h.theta, a.theta)
+    finally:
+        for m_ in (rp, re_, o1):
+            close_forcing_file(m_)
+        del rp, re_, o1, o2
 
     class FailingSource:  # a forcing source whose read fails part way (a truncated file, an I/O error): surfaces, never hangs
         ndim, shape, dtype = 2, pr.shape, pr.dtype

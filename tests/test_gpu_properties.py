@@ -15,8 +15,12 @@ checked exactly:
 
 Plus the accuracy of the lean fp64 log2 / exp2 / pow on the real hardware (the CPU simulator divides exactly where the
 device uses v_rcp_f64 + Newton, so only a GPU run measures the shipped arithmetic)."""
+import os
+
 import numpy as np
 import pytest
+
+from conftest import GOLDEN
 
 pytestmark = pytest.mark.gpu
 
@@ -248,6 +252,19 @@ def test_lean_division_and_pairwise_polynomials_on_hardware():
     ref = a.astype(L) / b.astype(L)
     assert float(np.max(np.abs(got - ref) / np.abs(ref))) <= 2.3e-16
     assert float(lg.leaf_batch("div", [0.0], [3.0], **{k: v[:1] for k, v in kw.items()})[0]) == 0.0
+    # the edges: a zero, infinite or denormal divisor, an infinite dividend -- the IEEE quotient, not the NaN of a Newton step
+    # through inf * 0 (an overflowed (alpha h)^n in theta_from_h must give theta_r)
+    ea = np.array([1.0, 1.0, 1.0, 1.0, 0.0, np.inf, np.inf, 3.0, -2.0, 1e300, 0.0])
+    eb = np.array([0.0, np.inf, 5e-324, 1e308, np.inf, 2.0, 1e308, -0.0, 1e-310, 1e-300, 0.0])
+    ke = {k: v[:len(ea)] for k, v in kw.items()}
+    got = lg.leaf_batch("div", ea, eb, **ke).cpu().numpy()
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        ref = ea / eb
+    assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.isnan(ref).sum() == 1  # only 0 / 0
+    ok = ~np.isnan(ref)
+    assert np.array_equal(np.isinf(got[ok]), np.isinf(ref[ok])) and np.array_equal(np.sign(got[ok]), np.sign(ref[ok]))
+    fin = ok & np.isfinite(ref) & (ref != 0)
+    assert np.allclose(got[fin], ref[fin], rtol=1e-15, atol=0)
     x = np.concatenate([np.exp(rng.uniform(np.log(1e-12), np.log(1e12), n // 2)), 1.0 + rng.uniform(-0.3, 0.4, n // 2)])
     got = lg.leaf_batch("log2_pairwise", x, **kw).cpu().numpy().astype(L)
     ref = np.log2(x.astype(L))
@@ -297,6 +314,45 @@ def test_the_same_job_twice_is_bit_identical(which):
         o = eng.forward(pr, pe, series=("runoff", "infiltration"), check=False)
         runs.append((eng.status.clone(), o["runoff"].clone(), o["infiltration"].clone(), eng.theta.clone(), eng.depth.clone(),
                      eng.totals.clone()))
+    for r in runs[1:]:
+        for a, b in zip(runs[0], r):
+            assert torch.equal(torch.nan_to_num(a.double(), nan=-1.0), torch.nan_to_num(b.double(), nan=-1.0))
+
+
+@pytest.mark.parametrize("which", ["f32", "f64", "mixed"])
+@pytest.mark.parametrize("case", ["two_layers", "six_layers", "capacity_chain_16_and_32_slots"])
+def test_the_same_job_twice_is_bit_identical_other_kernels(case, which):
+    """... and the kernels the storm ensemble above does not reach: the two- and six-layer translation units, and -- under a pulsed
+    rain that grows up to ~30 wetting fronts per column -- the 16- and 32-slot members of the front-capacity chain, which pick up
+    the columns the 8-slot kernel hands over (persistent waves again: which wave integrates which block, and with what left in
+    its LDS and scratch from the block before, differs from run to run)."""
+    import lgar_py_amd as lg
+    name = {"two_layers": "two_layer_synth1", "six_layers": "six_layer_synth1", "capacity_chain_16_and_32_slots": "manyfronts_pulse_84"}[case]
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    N = 1 << 17  # 2 048 wavefronts: above the 1 024 of a small job, so the capacity chain runs (include/lgar.h)
+    rng = np.random.default_rng(11)
+    L = len(g["alpha"])
+    pert = lambda v: np.asarray(v, dtype=np.float64)[:, None] * (1.0 + 0.1 * (2.0 * rng.random((L, N)) - 1.0))
+    dt = torch.float32 if which == "f32" else torch.float64
+    kw = dict(geff_precision="f32") if which == "mixed" else {}
+    eng = lg.LgarEngine(pert(g["alpha"]), pert(g["n"]), pert(g["ksat"]), pert(g["theta_e"]), pert(g["theta_r"]),
+                        np.repeat(np.asarray(g["thickness"], dtype=np.float64)[:, None], N, 1), dt_h=float(g["dt_h"]),
+                        num_subcycles=int(g["num_subcycles"]), ponded_depth_max=float(g["pdm"]), initial_psi=float(g["initial_psi"]),
+                        wilting_point_psi=float(g["wilting_point_psi"]), nint=int(g["nint"]), dtype=dt, **kw)
+    sc = torch.tensor(0.7 + 0.6 * rng.random(N), device="cuda")
+    f = torch.tensor(g["forcing"], device="cuda")
+    pr = (f[:, 0:1] * sc[None, :]).to(dt).contiguous()
+    pe = f[:, 1:2].expand(-1, N).to(dt).contiguous()
+    runs = []
+    for k in range(3):
+        eng.reset()
+        o = eng.forward(pr, pe, series=("runoff", "infiltration"), check=False)
+        runs.append((eng.status.clone(), o["runoff"].clone(), o["infiltration"].clone(), eng.theta.clone(), eng.depth.clone(),
+                     eng.n_fronts.clone()))
+    if case.startswith("capacity_chain"):
+        ok = runs[0][0] == 0
+        assert int(runs[0][5][ok].max()) > 16 and int(((runs[0][5] > 8) & ok).sum()) > N // 10  # the 16- and 32-slot kernels ran
+    assert int((runs[0][0] == 0).sum()) > N // 2
     for r in runs[1:]:
         for a, b in zip(runs[0], r):
             assert torch.equal(torch.nan_to_num(a.double(), nan=-1.0), torch.nan_to_num(b.double(), nan=-1.0))

@@ -76,7 +76,8 @@ def test_forcing_csvs_to_mapped_files(tmp_path):
             if c % 2:
                 f.write("\n\n")  # the synth files end in blank lines
         paths.append(str(p))
-    got = forcing_csvs_to_files(paths, str(tmp_path / "p.npy"), str(tmp_path / "e.npy"), nsteps=24, dtype="float64")
+    got = forcing_csvs_to_files(paths, str(tmp_path / "p.npy"), str(tmp_path / "e.npy"), nsteps=24, dtype="float64",
+                                block_columns=2)  # (blocks of 2, 2 and 1 columns)
     assert got == (24, N)
     fp, fe = open_forcing_file(str(tmp_path / "p.npy")), open_forcing_file(str(tmp_path / "e.npy"))
     assert isinstance(fp, np.memmap) and fp.shape == (24, N)
@@ -85,3 +86,5 @@ def test_forcing_csvs_to_mapped_files(tmp_path):
         f.write("Time,P(mm/h),PET(mm/h)\n2020-01-01 00:00:00,1.0,0.1\n")
     with pytest.raises(ValueError, match="forcing rows"):
         forcing_csvs_to_files(paths, str(tmp_path / "p2.npy"), str(tmp_path / "e2.npy"))
+    # a failed conversion leaves nothing behind: neither partial outputs nor their temporaries
+    assert not [f for f in os.listdir(tmp_path) if f.startswith(("p2.npy", "e2.npy"))]
