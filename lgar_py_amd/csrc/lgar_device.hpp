@@ -29,6 +29,9 @@
 #define LGAR_KARG
 #endif
 
+#ifndef LGAR_T_BMEMO
+#define LGAR_T_BMEMO 0
+#endif
 namespace lgar {
 
 constexpr int WAVE = 64;
@@ -247,6 +250,7 @@ template <typename S, int POL = 0> __device__ __forceinline__ S theta_from_h_ap(
 template <typename S> __device__ __forceinline__ S se_from_theta(const LayerK<S> &l, S theta) {
   return (theta - l.tr) / (l.te - l.tr);
 }
+
 // calc_se_from_h, utils.py:115-131 (exactly 1 for |h| < 0.1)
 template <typename S, int POL = 0> __device__ __forceinline__ S se_from_h(const LayerK<S> &l, S h) {
   using R = real_t<S>;
@@ -263,6 +267,14 @@ template <typename S, int POL = 0> __device__ __forceinline__ S k_from_se(const 
   S op = pwq<S, POL>(base, l.m);
   S t = R(1.0) - op;
   return l.ksat * sq(se) * (t * t);
+}
+// ... at Se == 1 (the trapezoid's K under the |h| < 0.1 rule): Se^(1/m) is exactly 1, the base exactly 0 and nudged to 1e-12 --
+// calc_k_from_se's value and tangent, bit for bit, without the first pow
+template <typename S, int POL = 0> __device__ __forceinline__ S k_from_se_one(const LayerK<S> &l) {
+  using R = real_t<S>;
+  S op = pwq<S, POL>(S(R(1e-12)), l.m);
+  S t = R(1.0) - op;
+  return l.ksat * sq(S(R(1.0))) * (t * t);
 }
 // calc_h_from_se, utils.py:159-174
 template <typename S, int POL = 0> __device__ __forceinline__ S h_from_se(const LayerK<S> &l, S se) {
@@ -552,7 +564,7 @@ __device__ __forceinline__ S geff_fused(const LayerK<S> &l, S theta1, S theta2, 
     LGAR_MEASURE_POINT(CLK, 25)
     h_i = h_from_se(l, se_i);
     h_f = h_from_se(l, se_f);
-    k_sat1 = k_from_se(l, S(R(1.0)));
+    k_sat1 = k_from_se_one(l);
     k1 = k_from_se(l, se_i);
     LGAR_MEASURE_POINT(CLK, 26)
   }
@@ -1067,6 +1079,8 @@ __device__ __forceinline__ double geff_mixed_core(const LayerK<double> &l, doubl
 // NOT inlined: its callers are the two call sites that run rarely (insert_water on a memo miss: 16 % of the wave-level
 // evaluations; the dry-depth evaluation: 1 %) -- calc_dzdt, the hot one, has its own inlined copy (geff_mixed_heads).  Two fewer
 // copies of the trapezoid in the kernel: 93 -> 52 spilled registers, and the size of the code is part of its speed (build.py).
+// (Round 5, same-box A/B: inlined it is 1.7 % slower -- 30.2 against 29.7 ms, 130 spilled registers against 86 -- although the
+// register saves around this call are 3.6 GB of the kernel's 13.5 GB of scratch write-back per launch.)
 __device__ __attribute__((noinline)) double geff_mixed(const LayerK<double> &l, double theta1, double theta2, int nint) {
   const double se_i = se_from_theta(l, theta1);
   const double se_f = se_from_theta(l, theta2);
@@ -1252,6 +1266,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
   S post_mass;
   bool post_mass_valid = false;
   bool post_event = false;
+  bool psi_rewritten = false;  // a dry-over-wet deletion below the top layer rewrote theta and psi of the fronts above (q13)
   S aet_psi_wp_memo;          // calc_aet's half-uptake head of this column (a function of the top layer's parameters only)
   bool aet_psi_wp_known = false;
   bool count_geff = false;              // measurement: count wave-level Geff evaluations in the unused upper bits of `status`
@@ -1888,12 +1903,22 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
       if (i < c.nf0 - 1) {
         if (i == last || feq(i, last)) {
           // deepest front of a layer: psi continuity with the layer below
+#if LGAR_T_BMEMO
+          // (fast modes: a boundary front whose psi IS the psi below, bit for bit, took its theta from that very psi the last
+          // time round -- nothing to do; decided per lane, skipped when no column of the wavefront has anything to do.  The
+          // boundary above an untouched layer stays like that for the whole run.)
+          const bool fresh = (MODE != 0) && same_bits(F.PS(i), F.PS(i + 1));
+          if (!fresh) {
+#endif
           S ap;
           F.TH(i) = theta_from_h_ap<S, POL>(lk, F.PS(i + 1), ap);
           F.PS(i) = F.PS(i + 1);
           if constexpr (MODE != 0 && sizeof(R) == 8) {
             if (__builtin_expect(val(ap) < R(1e-6), 0)) c.near_sat |= 1u << i;
           }
+#if LGAR_T_BMEMO
+          }
+#endif
           LGAR_MEASURE_POINT(CLK, 20)
         } else if constexpr (K == 0) {
           S prior_mass = oc_z * (oc_th - c.on_th);
@@ -2162,6 +2187,9 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
       F.Z(i) = cumk;
       F.TH(nx) = theta_new;
       F.PS(nx) = F.PS(i);
+      // (fast modes: the reference's update_psi re-derives the new front's psi from its theta at the end of the move -- nothing
+      // reads it before -- and right after a crossing that round trip is not a no-op: the front is all but saturated)
+      if constexpr (MODE != 0) F.PS(nx) = h_from_se<S, POL>(ln, se_from_theta(ln, theta_new));
       F.Z(nx) = depth_new;
       F.DZ(nx) = F.DZ(i);
       F.DZ(i) = S(R(0.0));
@@ -2205,6 +2233,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
       S before = mass_balance();
       fdel(i);  // the next front now sits at index i
       if (k > 0) {
+        psi_rewritten = true;
         int found = 0;
         while (found < nf && !feq(found, i)) found++;
         if (found >= nf) status |= LGAR_ST_STRUCT;
@@ -2289,6 +2318,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
     else pending = front_event_pending();
     if (__builtin_expect(pending, 0)) {
       post_mass_valid = false;
+      psi_rewritten = false;
       for (int pass = 0; pass < 2; pass++) {
         merge_fronts();
         if (pass == 0) cross_layer_boundary();
@@ -2298,7 +2328,10 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
       if (ab(val(mass_change)) > R(1e-7)) aet = aet - mass_change;
       // the passes can leave psi inconsistent with theta (dry-over-wet in a deeper layer writes the psi of ANOTHER
       // layer's theta into the fronts above it, Layer.py:1117-1143): the reference's update_psi repairs that
-      if constexpr (MODE != 0) update_psi();
+      // ... every front a merge or a crossing touched carries psi = h(Se(theta)) already (each pass sets it); only that rewrite
+      // needs the reference's full pass -- and a column with a near-saturated boundary front (below), whose bit may no longer
+      // sit at the front's index after a deletion
+      if constexpr (MODE != 0) { if (psi_rewritten || near_sat_fronts != 0u) update_psi(); }
     } else if constexpr (MODE != 0 && sizeof(R) == 8) {
       // A layer's deepest front takes the psi of the front below and theta(psi) of its own layer (Layer.py:389-418); the
       // reference's update_psi then re-derives psi from that theta.  The round trip returns psi to ~eps / (alpha psi)^n
