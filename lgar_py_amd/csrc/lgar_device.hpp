@@ -29,9 +29,6 @@
 #define LGAR_KARG
 #endif
 
-#ifndef LGAR_T_BMEMO
-#define LGAR_T_BMEMO 0
-#endif
 namespace lgar {
 
 constexpr int WAVE = 64;
@@ -661,17 +658,8 @@ __device__ __forceinline__ S geff_fused(const LayerK<S> &l, S theta1, S theta2, 
 // dh/2 (K_0 + K_n + 2 sum of interior nodes): one packed add per node pair.  Interior nodes sit at h_i + j dh (no running
 // sum: it drifts by cm for very dry soil); the last node is h_f itself, which dominates the integral for dry soil.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-template <> __device__ __forceinline__ float geff<float>(const LayerK<float> &l, float theta1, float theta2, int nint) {
-  const float se_i = se_from_theta(l, theta1);
-  const float se_f = se_from_theta(l, theta2);
-  // h(Se) of both end points (calc_h_from_se, utils.py:159-174) with one reciprocal of alpha
-  const float inv_alpha = 1.0f / l.alpha;
-  auto head = [&](float se) {
-    float base = pw(se, -l.inv_m) - 1.0f;
-    if (fabsf(base) <= 1e-8f) base = base + 1e-12f;
-    return inv_alpha * pw(base, l.inv_n);
-  };
-  const float h_i = head(se_i), h_f = head(se_f);
+// (the trapezoid given its two heads; kn_out, when asked for: K_r of the wet end node)
+__device__ __forceinline__ float geff_f32_from_heads(const LayerK<float> &l, float h_i, float h_f, int nint, float *kn_out = nullptr) {
   const float dh = (h_f - h_i) * (1.0f / float(nint));
   const float nm1 = l.n - 1.0f;
   const float hm = -0.5f * l.m;
@@ -765,7 +753,20 @@ template <> __device__ __forceinline__ float geff<float>(const LayerK<float> &l,
   float sum = acc.x + acc.y;
   if (M & 1) sum += node(__builtin_fmaf(float(M), dx, x0));
   const float k0 = node(x0), kn = node(l.alpha * h_f);
+  if (kn_out != nullptr) *kn_out = kn;
   return fabsf((0.5f * dh) * ((k0 + kn) + 2.0f * sum));
+}
+template <> __device__ __forceinline__ float geff<float>(const LayerK<float> &l, float theta1, float theta2, int nint) {
+  const float se_i = se_from_theta(l, theta1);
+  const float se_f = se_from_theta(l, theta2);
+  // h(Se) of both end points (calc_h_from_se, utils.py:159-174) with one reciprocal of alpha
+  const float inv_alpha = 1.0f / l.alpha;
+  auto head = [&](float se) {
+    float base = pw(se, -l.inv_m) - 1.0f;
+    if (fabsf(base) <= 1e-8f) base = base + 1e-12f;
+    return inv_alpha * pw(base, l.inv_n);
+  };
+  return geff_f32_from_heads(l, head(se_i), head(se_f), nint);
 }
 template <> __device__ __forceinline__ double geff<double>(const LayerK<double> &l, double t1, double t2, int nint) {
   return geff_fused<double>(l, t1, t2, nint);
@@ -1903,22 +1904,18 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
       if (i < c.nf0 - 1) {
         if (i == last || feq(i, last)) {
           // deepest front of a layer: psi continuity with the layer below
-#if LGAR_T_BMEMO
           // (fast modes: a boundary front whose psi IS the psi below, bit for bit, took its theta from that very psi the last
-          // time round -- nothing to do; decided per lane, skipped when no column of the wavefront has anything to do.  The
+          // time round -- nothing to do; decided per lane, the evaluation skipped when no column of the wavefront needs it.  The
           // boundary above an untouched layer stays like that for the whole run.)
           const bool fresh = (MODE != 0) && same_bits(F.PS(i), F.PS(i + 1));
           if (!fresh) {
-#endif
-          S ap;
-          F.TH(i) = theta_from_h_ap<S, POL>(lk, F.PS(i + 1), ap);
-          F.PS(i) = F.PS(i + 1);
-          if constexpr (MODE != 0 && sizeof(R) == 8) {
-            if (__builtin_expect(val(ap) < R(1e-6), 0)) c.near_sat |= 1u << i;
+            S ap;
+            F.TH(i) = theta_from_h_ap<S, POL>(lk, F.PS(i + 1), ap);
+            F.PS(i) = F.PS(i + 1);
+            if constexpr (MODE != 0 && sizeof(R) == 8) {
+              if (__builtin_expect(val(ap) < R(1e-6), 0)) c.near_sat |= 1u << i;
+            }
           }
-#if LGAR_T_BMEMO
-          }
-#endif
           LGAR_MEASURE_POINT(CLK, 20)
         } else if constexpr (K == 0) {
           S prior_mass = oc_z * (oc_th - c.on_th);
@@ -2613,6 +2610,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
             fronts_done = true;
           }
         }
+        LGAR_MEASURE_POINT(F32_HEADS_FROM_PSI, lk, i, g, ki, fronts_done)
         if (!fronts_done) {
           g = capillary_drive(lk, theta_1, theta_2, 1);
           ki = front_k(i, lk);

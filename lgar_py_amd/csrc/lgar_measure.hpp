@@ -203,3 +203,22 @@ static __shared__ unsigned long long lgar_dbg_clk_last;
 #else
 #define LGAR_POINT_POISON_LDS(lds, slot)
 #endif
+
+// ---- the fp32 kernel's calc_dzdt with the trapezoid's heads taken from the fronts' own psi and K(theta_i) from the wet end node
+// (-DLGAR_F32_HEADS_FROM_PSI): what the mixed-precision kernel does, tried on the fp32 kernel in round 4, where it made the
+// results differ from run to run.  Kept as a measurement variant to study that (tools/spill_determinism.sh).
+#ifdef LGAR_F32_HEADS_FROM_PSI
+#define LGAR_POINT_F32_HEADS_FROM_PSI(lk, i, g, ki, fronts_done)                                    \
+  if constexpr (sizeof(S) == 4 && sizeof(R) == 4 && MODE != 0) {                                   \
+    if (!G->closed_form) {                                                                         \
+      float kn_ = 0.0f;                                                                            \
+      LGAR_COUNT_GEFF_CALL(1)                                                                      \
+      g = geff_f32_from_heads(lk, F.PS(i + 1), F.PS(i), G->nint, &kn_);                            \
+      ki = lk.ksat * kn_;                                                                          \
+      if (i == 0 && new_front_frozen) ki = ki * G->frozen;                                         \
+      fronts_done = true;                                                                          \
+    }                                                                                              \
+  }
+#else
+#define LGAR_POINT_F32_HEADS_FROM_PSI(lk, i, g, ki, fronts_done)
+#endif
