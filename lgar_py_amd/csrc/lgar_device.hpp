@@ -594,7 +594,9 @@ __device__ __forceinline__ S geff_fused(const LayerK<S> &l, S theta1, S theta2, 
   // h_i to h_f): a wave-uniform count of leading nodes that no lane needs to test runs select-free.
   int n_safe = nint;
   if (i < nint) {
-    const R jf = (val(h_i) - R(0.1)) / -val(dh) - R(2.0);
+    // (node j sits at h_i + j dh: nodes up to floor((h_i - 0.1) / -dh) - 1 lie a whole interval above the cut, far more than the
+    // running sum's rounding can move them)
+    const R jf = (val(h_i) - R(0.1)) / -val(dh) - R(1.0);
     const int safe = (jf > R(0.0)) ? ((jf < R(nint)) ? int(jf) : nint) : 0;  // NaN (dh == 0) -> 0
     if (any_lane(safe < nint) != 0ull) {
       n_safe = 0;
