@@ -1084,7 +1084,12 @@ __device__ __forceinline__ double geff_mixed_core(const LayerK<double> &l, doubl
 // copies of the trapezoid in the kernel: 93 -> 52 spilled registers, and the size of the code is part of its speed (build.py).
 // (Round 5, same-box A/B: inlined it is 1.7 % slower -- 30.2 against 29.7 ms, 130 spilled registers against 86 -- although the
 // register saves around this call are 3.6 GB of the kernel's 13.5 GB of scratch write-back per launch.)
-__device__ __attribute__((noinline)) double geff_mixed(const LayerK<double> &l, double theta1, double theta2, int nint) {
+// (The layer's parameters travel as eight scalar arguments -- in registers.  A LayerK by reference is a struct the caller must
+// first build in scratch memory: 64 bytes per lane stored at every call and loaded back by the callee, and by value the
+// aggregate is past the 16 argument registers the ABI gives a struct, so it would go through scratch all the same.)
+__device__ __attribute__((noinline)) double geff_mixed(double alpha, double n, double m, double inv_m, double inv_n, double ksat, double te,
+                                                       double tr, double theta1, double theta2, int nint) {
+  const LayerK<double> l{alpha, n, m, inv_m, inv_n, ksat, te, tr};
   const double se_i = se_from_theta(l, theta1);
   const double se_f = se_from_theta(l, theta2);
   // K_r at Se == 1 (the 1e-12 nudge of calc_k_from_se): (1 - (1e-12)^m)^2
@@ -1101,8 +1106,10 @@ __device__ __attribute__((noinline)) double geff_mixed(const LayerK<double> &l, 
   return geff_mixed_core(l, h_i, h_f, k0, kn_own, ksat1, nint);
 }
 // ... for cooperating lanes (MODE 6: insert_water, the dry-depth evaluation): the same ends, the interior split over the lanes
-__device__ __attribute__((noinline)) double geff_mixed_coop(const LayerK<double> &l, double theta1, double theta2, int nint, double *tab,
+__device__ __attribute__((noinline)) double geff_mixed_coop(double alpha, double n, double m, double inv_m, double inv_n, double ksat,
+                                                            double te, double tr, double theta1, double theta2, int nint, double *tab,
                                                             int lanes, int r) {
+  const LayerK<double> l{alpha, n, m, inv_m, inv_n, ksat, te, tr};
   const double se_i = se_from_theta(l, theta1);
   const double se_f = se_from_theta(l, theta2);
   const double tsat = 1.0 - ex2p(l.m * LGAR_LOG2_1EM12);
@@ -1251,6 +1258,17 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
   int status;
   S ponded_water, previous_precip, ending_volume;
   S giuh_q[LGAR_GMAX];
+  // MODE 3, one lane per column: the GIUH queue is not held in registers at all.  It is touched once per sub-step and only
+  // on storm steps -- which made its 16 registers the allocator's first spill victims, and a spilled read-modify-write is a
+  // scratch store every time (5.5 of the kernel's 13.5 GB of write traffic, profiles/r05/ablate_giuh_queue.jsonl).  The
+  // queue is updated in place in the column's own rows of the state arrays (`scalars` rows 3.., coalesced across the lanes),
+  // where it is loaded from and stored to anyway; a flag remembers whether anything is queued (giuh_live, the reference's
+  // `sum(queue) > 0` test evaluated when the queue was last written, lgar/giuh.py:8-20).
+  static constexpr bool GIUH_MEM = (MODE == 3) && (sizeof(S) == sizeof(R));
+  static constexpr int DEAD = LGAR_ST_BOTTOM | LGAR_ST_OVERFLOW | LGAR_ST_STRUCT;  // forward() leaves such a column alone
+  R *giuh_mem = nullptr;   // &scalars[3 * N + c]
+  size_t giuh_stride = 0;  // N
+  bool giuh_live = false;
   // K(theta) is not kept per front: the reference refreshes it from theta for every front but the deepest at the end
   // of each move (update_psi, Layer.py:1166-1170) and reads it only in calc_dzdt, so it is computed there, for moving
   // fronts only.  k_deepest is the one K that is never refreshed (the domain's deepest front keeps its initial K);
@@ -1301,10 +1319,10 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
       if (share_lanes > 1 && !G->closed_form) return geff_fused<S>(lk, theta1, theta2, G->nint, xchg, share_lanes, coop_rank, riders);
     }
     if constexpr (MODE == 6 && sizeof(S) == 8 && sizeof(R) == 8) {  // mixed-precision trapezoid, its groups of nodes split over the lanes
-      if (share_lanes > 1 && !G->closed_form) return geff_mixed_coop(lk, theta1, theta2, G->nint, xchg, share_lanes, coop_rank);
+      if (share_lanes > 1 && !G->closed_form) return geff_mixed_coop(val(lk.alpha), val(lk.n), val(lk.m), val(lk.inv_m), val(lk.inv_n), val(lk.ksat), val(lk.te), val(lk.tr), theta1, theta2, G->nint, xchg, share_lanes, coop_rank);
     }
     if constexpr (mixed_mode(MODE) && sizeof(S) == 8 && sizeof(R) == 8) {  // plain double, LgarDims.geff_mode = 1
-      if (!G->closed_form) return geff_mixed(lk, theta1, theta2, G->nint);
+      if (!G->closed_form) return geff_mixed(val(lk.alpha), val(lk.n), val(lk.m), val(lk.inv_m), val(lk.inv_n), val(lk.ksat), val(lk.te), val(lk.tr), theta1, theta2, G->nint);
     }
     return G->closed_form ? geff_closed<S, POL>(lk, theta1, theta2) : geff(lk, theta1, theta2, G->nint);
   }
@@ -2801,7 +2819,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
     if (is_nan(val(precip)) || is_nan(val(pet))) status |= LGAR_ST_NAN;
     S ending_volume_sub = ending_volume;
     for (int sub = 0; sub < G->nsub; sub++) {
-      if (status & (LGAR_ST_BOTTOM | LGAR_ST_OVERFLOW | LGAR_ST_STRUCT)) return;  // dead column
+      if (status & DEAD) return;  // dead column
       new_front_frozen = false;
       post_mass_valid = false;
       S precip_sub = precip * dt;
@@ -2880,6 +2898,27 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
       // GIUH, models/dpLGAR.py:292-298 and lgar/giuh.py:8-20
       // (queue entries from the ng-th on are zero and stay zero -- nothing is ever added to them and zeros shift in from above --
       // so the sum and the shift need no test against ng: the same values, eight adds and eight moves)
+      if constexpr (GIUH_MEM) {
+        if (giuh_live || val(runoff_sub) > R(0.0)) {
+          const int ng = G->ng;
+          S q[LGAR_GMAX];
+#pragma unroll
+          for (int i = 0; i < LGAR_GMAX; i++) q[i] = (i < ng) ? S(giuh_mem[(size_t)i * giuh_stride]) : S(R(0.0));
+#pragma unroll
+          for (int i = 0; i < LGAR_GMAX; i++) if (i < ng) q[i] = q[i] + (G->giuh[i] * runoff_sub);
+          const S now = q[0];
+          R qsum = R(0.0);
+#pragma unroll
+          for (int i = 0; i < LGAR_GMAX; i++) {
+            const S shifted = (i + 1 < LGAR_GMAX) ? q[(i + 1 < LGAR_GMAX) ? i + 1 : i] : S(R(0.0));
+            qsum += val(shifted);  // (the next sub-step's test, summed in its order)
+            if (i < ng) giuh_mem[(size_t)i * giuh_stride] = val(shifted);
+          }
+          giuh_live = qsum > R(0.0);
+          a_giuh = a_giuh + now;
+          a_disch = a_disch + now;
+        }
+      } else {
       R qsum = R(0.0);
 #pragma unroll
       for (int i = 0; i < LGAR_GMAX; i++) qsum += val(giuh_q[i]);
@@ -2892,6 +2931,7 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
         giuh_q[LGAR_GMAX - 1] = S(R(0.0));
         a_giuh = a_giuh + now;
         a_disch = a_disch + now;
+      }
       }
       // NaN anywhere in the front table (the reference raises at the pow that produces it, physics/utils.py:17-27).
       // MODE 1: a NaN depth or theta reaches the column mass just computed, a NaN psi reaches a theta within a step.

@@ -43,15 +43,18 @@ template <typename R> struct KArgs {
 // Per-call sums of the accumulators that fit in the wave's LDS budget next to the front table.  They are touched once per
 // forcing step, which makes them the register allocator's first spill victims -- and a spilled read-modify-write is
 // scratch (HBM) write traffic on every step.  The 8-slot kernels have 10 KB (fp32, 4 waves/SIMD) / 20 KB (fp64, 2 waves/SIMD)
-// of LDS per wave: 8.5 / 16.5 KB of fronts + 6 rows of sums = exactly 10 / 20 KB; percolation (zero in the reference's
-// mode) stays in a register, discharge is the same sum as giuh_runoff.
+// of LDS per wave: fp32, 8.5 KB of fronts + 6 rows of sums = exactly 10 KB, percolation (zero in the reference's mode) stays
+// in a register; fp64, 16.5 KB of fronts + 7 rows = exactly 20 KB (the register pair of the seventh was stored to scratch on
+// every step: 8 of the 28 bytes per column and step the mixed-precision kernel still spilled in round 5).  Discharge is
+// the same sum as giuh_runoff.
 template <typename S, int FMAX> struct LdsSums {
-  static constexpr int rows = (FMAX <= LGAR_CAP_SMALL) ? 6 : 8;
+  static constexpr int rows = (FMAX <= LGAR_CAP_SMALL) ? (sizeof(S) == 8 ? 7 : 6) : 8;
 };
 
 // LDS row of accumulator j's per-call sum, or -1 if it stays in a register: with 6 rows the one left out is percolation
+// (with 7 it has the last row)
 template <int SR> __device__ __forceinline__ constexpr int sum_row(int j) {
-  return (SR >= 8) ? (j < 8 ? j : -1) : ((j < 5) ? (j < SR ? j : -1) : ((j == 6 && SR >= 6) ? 5 : -1));
+  return (SR >= 8) ? (j < 8 ? j : -1) : ((j < 5) ? (j < SR ? j : -1) : ((j == 6 && SR >= 6) ? 5 : ((j == 5 && SR >= 7) ? 6 : -1)));
 }
 
 template <typename S, int FMAX, int SUMROWS = LdsSums<S, FMAX>::rows, int STRIDE = WAVE> struct WaveLDS {
@@ -138,8 +141,10 @@ __device__ __forceinline__ void store_state(const LGAR_KARG KArgs<R> &a, size_t 
   a.scalars[0 * N + c] = col.ponded_water;
   a.scalars[1 * N + c] = col.previous_precip;
   a.scalars[2 * N + c] = col.ending_volume;
+  if constexpr (!Column<R, NL, FMAX, MODE>::GIUH_MEM) {  // (GIUH_MEM: the queue lives there already)
 #pragma unroll
-  for (int i = 0; i < LGAR_GMAX; i++) a.scalars[(3 + i) * N + c] = col.giuh_q[i];
+    for (int i = 0; i < LGAR_GMAX; i++) a.scalars[(3 + i) * N + c] = col.giuh_q[i];
+  }
   a.status[c] = status_word;
 }
 
@@ -205,8 +210,17 @@ __device__ __forceinline__ void forward_lane(const LGAR_KARG KArgs<R> *ap, size_
   col.ponded_water = a.scalars[0 * N + c];
   col.previous_precip = a.scalars[1 * N + c];
   col.ending_volume = a.scalars[2 * N + c];
+  if constexpr (Column<R, NL, FMAX, MODE>::GIUH_MEM) {
+    col.giuh_mem = &a.scalars[3 * N + c];
+    col.giuh_stride = N;
+    R qsum = R(0);
 #pragma unroll
-  for (int i = 0; i < LGAR_GMAX; i++) col.giuh_q[i] = a.scalars[(3 + i) * N + c];
+    for (int i = 0; i < LGAR_GMAX; i++) qsum += a.scalars[(3 + i) * N + c];
+    col.giuh_live = qsum > R(0);
+  } else {
+#pragma unroll
+    for (int i = 0; i < LGAR_GMAX; i++) col.giuh_q[i] = a.scalars[(3 + i) * N + c];
+  }
   col.status = status;
   if (nf < NL) col.status |= LGAR_ST_STRUCT;  // not a state lgar_state_init / lgar_forward produced: column is skipped
   col.k_deepest = (nf > 0) ? a.k[(size_t)(nf - 1) * N + c] : R(0);

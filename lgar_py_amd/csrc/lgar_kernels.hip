@@ -43,7 +43,7 @@ template <typename R> __global__ void lgar_leaf_kernel(LeafArgs<R> a) {
     case 8: r = ex2p(x); break;
     case 9: r = pw(x, y); break;
     case 10:
-      if constexpr (sizeof(R) == 8) r = geff_mixed(l, x, y, a.nint);
+      if constexpr (sizeof(R) == 8) r = geff_mixed(l.alpha, l.n, l.m, l.inv_m, l.inv_n, l.ksat, l.te, l.tr, x, y, a.nint);
       else r = geff(l, x, y, a.nint);
       break;
     case 11: r = dv<0>(x, y); break;        // the fast modes' quotient (double precision: lean_div)

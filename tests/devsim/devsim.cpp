@@ -155,7 +155,7 @@ void devsim_geff(int variant, int n, const double *theta1, const double *theta2,
     l.alpha = alpha[i]; l.n = nn[i]; l.m = 1.0 - 1.0 / l.n; l.inv_m = 1.0 / l.m; l.inv_n = 1.0 / l.n;
     l.ksat = ksat[i]; l.te = te[i]; l.tr = tr[i];
     if (variant == 0) out[i] = geff_fused<double>(l, theta1[i], theta2[i], nint);
-    else if (variant == 1) out[i] = geff_mixed(l, theta1[i], theta2[i], nint);
+    else if (variant == 1) out[i] = geff_mixed(l.alpha, l.n, l.m, l.inv_m, l.inv_n, l.ksat, l.te, l.tr, theta1[i], theta2[i], nint);
     else if (variant == 2) out[i] = geff_literal<double, 1>(l, theta1[i], theta2[i], nint);
     else {
       LayerK<float> f;
