@@ -73,15 +73,47 @@ __device__ __forceinline__ double wave_sum(double v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
   return v;
 }
+// Atomic adds to a WAVE-UNIFORM address, nothing returned.  Such an atomic is encoded as scalar base + a vector offset of zero;
+// written in C++ the compiler keeps ONE zero register for all of them, alive from the kernel's first atomic to its last --
+// across all of the column physics -- and the allocator of the 8-slot fp64 kernels kept it by storing it to scratch at the top
+// of every step (8 bytes per column and step).  Here the zero is made where it is used.  (Those kernels only -- forward_lane's
+// PARK: in the fp32 kernel, which does not spill the zero, the same change costs 1.7 % through register allocation, measured.)
+__device__ __forceinline__ void atomic_add_uniform(double *p, double v) {
+  unsigned z;
+  asm volatile("v_mov_b32 %0, 0\n\tglobal_atomic_add_f64 %0, %1, %2" : "=&v"(z) : "v"(v), "s"(p) : "memory");
+}
+__device__ __forceinline__ void atomic_add_uniform(unsigned long long *p, unsigned long long v) {
+  unsigned z;
+  asm volatile("v_mov_b32 %0, 0\n\tglobal_atomic_add_x2 %0, %1, %2" : "=&v"(z) : "v"(v), "s"(p) : "memory");
+}
+__device__ __forceinline__ void atomic_add_uniform(unsigned *p, unsigned v) {
+  unsigned z;
+  asm volatile("v_mov_b32 %0, 0\n\tglobal_atomic_add %0, %1, %2" : "=&v"(z) : "v"(v), "s"(p) : "memory");
+}
 __device__ __forceinline__ void atomic_add(double *p, double v) { atomicAdd(p, v); }
 __device__ __forceinline__ void atomic_add(unsigned long long *p, unsigned long long v) { atomicAdd(p, v); }
 __device__ __forceinline__ void atomic_add(unsigned *p, unsigned v) { atomicAdd(p, v); }
 #else
 __device__ __forceinline__ double wave_sum(double v) { return v; }
 __device__ __forceinline__ void atomic_add(double *p, double v) { *p += v; }
+__device__ __forceinline__ void atomic_add_uniform(double *p, double v) { *p += v; }
+__device__ __forceinline__ void atomic_add_uniform(unsigned long long *p, unsigned long long v) { *p += v; }
+__device__ __forceinline__ void atomic_add_uniform(unsigned *p, unsigned v) { *p += v; }
 __device__ __forceinline__ void atomic_add(unsigned long long *p, unsigned long long v) { *p += v; }
 __device__ __forceinline__ void atomic_add(unsigned *p, unsigned v) { *p += v; }
 #endif
+
+// a lane's integer in a register, or (PARKED) in the lane's scratch memory: every get() a load, every set() a store
+template <bool PARKED> struct LaneInt {
+  int v;
+  __device__ __forceinline__ int get() const { return v; }
+  __device__ __forceinline__ void set(int x) { v = x; }
+};
+template <> struct LaneInt<true> {
+  volatile int v;
+  __device__ __forceinline__ int get() const { return v; }
+  __device__ __forceinline__ void set(int x) { v = x; }
+};
 
 // the kernel's argument block where it lies (kernarg segment); `launder` makes the compiler forget what it has already
 // loaded through the pointer, so values needed again later are re-read (one scalar load) rather than kept or spilled
@@ -244,12 +276,22 @@ __device__ __forceinline__ void forward_lane(const LGAR_KARG KArgs<R> *ap, size_
 
   // the column is integrated for steps t_begin <= t < t_stop; t_stop < T: handed to the next kernel of the chain at
   // t_stop (or, t_stop = -1, stopped for good before its first step); t_stop <= t_begin: the state in HBM is left as it is
-  int t_stop = a.T;
+  // (fp64 kernels of the smallest capacity: t_stop is PARKED in scratch memory -- read at the top of every step, written at a
+  // hand-over only.  In a register it lives across all of the column physics, and the allocator of these kernels, 60 registers
+  // short, kept it by storing it to scratch at the top of every step: 4 of the 20 bytes per column and step still spilled.)
+  constexpr bool PARK = (sizeof(R) == 8) && (FMAX <= LGAR_CAP_SMALL) && !coop_mode(MODE);
+  LaneInt<PARK> t_stop_at;
   bool overflow_on_load = false;
-  if (t_begin < a.T && nf_stored > cap) {
-    // more fronts than this kernel can hold: next kernel of the chain, or (last kernel) front overflow
-    if (a.chain_last) { overflow_on_load = true; t_stop = -1; } else t_stop = t_begin;
+  {
+    int t_stop = a.T;
+    if (t_begin < a.T && nf_stored > cap) {
+      // more fronts than this kernel can hold: next kernel of the chain, or (last kernel) front overflow
+      if constexpr (PARK) t_stop = a.chain_last ? -1 : t_begin;
+      else if (a.chain_last) { overflow_on_load = true; t_stop = -1; } else t_stop = t_begin;
+    }
+    t_stop_at.set(t_stop);
   }
+  if constexpr (PARK) overflow_on_load = t_begin < a.T && nf_stored > cap && a.chain_last;
   if (overflow_on_load) {
     col.status |= LGAR_ST_OVERFLOW;
     // no step of this column will run: its rows of the requested series read as zero (lgar_basin_reduce_kernel sums them).
@@ -305,11 +347,11 @@ __device__ __forceinline__ void forward_lane(const LGAR_KARG KArgs<R> *ap, size_
       pet = a.pet[(size_t)t * Nf + cf];
     }
     LGAR_MEASURE_POINT(CLK, 9)
-    bool active = (t >= t_begin) && (t < t_stop);
+    bool active = (t >= t_begin) && (t < t_stop_at.get());
     if (active && !a.chain_last && col.nf + a.G.nsub > FMAX) {
       // this step could outgrow the kernel's front capacity: hand the column over, state as of the end of step t-1
       active = false;
-      t_stop = t;
+      t_stop_at.set(t);
     }
     if (any_lane(active) == 0ull) continue;
     if (active) col.forward(precip, pet);
@@ -335,7 +377,10 @@ __device__ __forceinline__ void forward_lane(const LGAR_KARG KArgs<R> *ap, size_
       for (int j = 0; j < LGAR_NACC; j++)
         if (a.basin_mask & (1u << j)) {
           const double s = wave_sum(w * (double)acc[j]);
-          if (lane == 0) atomic_add(&a.basin[(size_t)j * T + t], s);
+          if (lane == 0) {
+            if constexpr (PARK) atomic_add_uniform(&a.basin[(size_t)j * T + t], s);
+            else atomic_add(&a.basin[(size_t)j * T + t], s);
+          }
         }
     }
     if (active) {
@@ -357,16 +402,23 @@ __device__ __forceinline__ void forward_lane(const LGAR_KARG KArgs<R> *ap, size_
     // measurement: wave-level Geff evaluations (the dominant instruction stream) of this block, counted above the fault
     // bits of the lanes' status words
     const double calls = wave_sum((double)((unsigned)col.status >> LGAR_ST_STEP_SHIFT));
-    if (lane == 0 && calls > 0.0) atomic_add(&z.counters[0], (unsigned long long)calls);
+    if (lane == 0 && calls > 0.0) {
+      if constexpr (PARK) atomic_add_uniform(&z.counters[0], (unsigned long long)calls);
+      else atomic_add(&z.counters[0], (unsigned long long)calls);
+    }
   }
   col.status &= LGAR_ST_FAULT_MASK;
+  const int t_stop = t_stop_at.get();
   if (t_begin >= z.T) return;  // not this kernel's column (or a padding lane)
   if (!leader) return;  // the column's results are stored by the leader of its group of cooperating lanes
   if (z.pending_out != nullptr) {
     // columns handed to the next kernel of the chain are counted, so that a next kernel with nothing to do (the usual
     // case) leaves after one load instead of scanning every status word
     const unsigned long long m = any_lane(t_stop >= 0 && t_stop < z.T);
-    if (m != 0ull && first_active_lane()) atomic_add(z.pending_out, (unsigned)__builtin_popcountll(m));
+    if (m != 0ull && first_active_lane()) {
+      if constexpr (PARK) atomic_add_uniform(z.pending_out, (unsigned)__builtin_popcountll(m));
+      else atomic_add(z.pending_out, (unsigned)__builtin_popcountll(m));
+    }
   }
   int word = col.status;
   if (t_stop >= 0 && t_stop < z.T) word |= LGAR_ST_RESUME | (int)((unsigned)t_stop << LGAR_ST_STEP_SHIFT);
