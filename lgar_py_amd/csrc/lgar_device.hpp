@@ -1324,10 +1324,14 @@ template <typename S, int NL, int FMAX, int MODE> struct Column {
       if (share_lanes > 1 && !G->closed_form) return geff_fused<S>(lk, theta1, theta2, G->nint, xchg, share_lanes, coop_rank, riders);
     }
     if constexpr (MODE == 6 && sizeof(S) == 8 && sizeof(R) == 8) {  // mixed-precision trapezoid, its groups of nodes split over the lanes
-      if (share_lanes > 1 && !G->closed_form) return geff_mixed_coop(val(lk.alpha), val(lk.n), val(lk.m), val(lk.inv_m), val(lk.inv_n), val(lk.ksat), val(lk.te), val(lk.tr), theta1, theta2, G->nint, xchg, share_lanes, coop_rank);
+      if (share_lanes > 1 && !G->closed_form)
+        return geff_mixed_coop(val(lk.alpha), val(lk.n), val(lk.m), val(lk.inv_m), val(lk.inv_n), val(lk.ksat), val(lk.te), val(lk.tr),
+                               theta1, theta2, G->nint, xchg, share_lanes, coop_rank);
     }
     if constexpr (mixed_mode(MODE) && sizeof(S) == 8 && sizeof(R) == 8) {  // plain double, LgarDims.geff_mode = 1
-      if (!G->closed_form) return geff_mixed(val(lk.alpha), val(lk.n), val(lk.m), val(lk.inv_m), val(lk.inv_n), val(lk.ksat), val(lk.te), val(lk.tr), theta1, theta2, G->nint);
+      if (!G->closed_form)
+        return geff_mixed(val(lk.alpha), val(lk.n), val(lk.m), val(lk.inv_m), val(lk.inv_n), val(lk.ksat), val(lk.te), val(lk.tr),
+                          theta1, theta2, G->nint);
     }
     return G->closed_form ? geff_closed<S, POL>(lk, theta1, theta2) : geff(lk, theta1, theta2, G->nint);
   }

@@ -143,3 +143,40 @@ def test_mixed_precision_is_an_fp64_fast_mode_option():
         lg.LgarEngine(*args, n_columns=4, dtype=torch.float64, search_mode=0, geff_precision="f32")
     with pytest.raises(lg.LgarError):
         lg.LgarEngine(*args, n_columns=4, geff_precision="half")
+
+
+@pytest.mark.parametrize("name", ["rand03", "synth2_phil", "bench_col10707", "five_layer_synth1", "manyfronts_pulse_84"])
+def test_mixed_giuh_queue_in_place_equals_queue_in_registers(name):
+    """The one-lane mixed-precision kernels (MODE 3) keep the GIUH queue in the column's rows of the `scalars` array and update it
+    there (lgar_device.hpp, Column::GIUH_MEM); the cooperating-lanes kernel (MODE 6) carries it in registers like every other
+    kernel.  Same additions in the same order: routed runoff, discharge, the stored queue and every other series must agree bit
+    for bit -- in one launch, and when the run is cut into launches that each start from a queue left in memory by the last
+    (the flag "something is queued" is then rebuilt from the loaded rows).  The routed runoff itself is checked against the
+    reference's golden series."""
+    import lgar_py_amd as lg
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    T = g["forcing"].shape[0]
+    ncol = 130  # two full waves and a ragged one
+    pr, pe = _forcing(g, ncol)
+    runs = {}
+    for tag, lanes, cuts in (("in_place", 1, (T,)), ("registers", 64, (T,)), ("in_place_cut", 1, (7, 31, 32, T))):
+        eng = _engine(g, ncol, torch.float64, geff_precision="f32", forward_lanes=lanes)
+        parts, t0 = [], 0
+        for t1 in cuts:
+            if t1 <= t0:
+                continue
+            out = eng.forward(pr[t0:t1].contiguous(), pe[t0:t1].contiguous(), series=lg.ACC_NAMES)
+            parts.append(np.stack([out[nm].cpu().numpy() for nm in lg.ACC_NAMES], 2))
+            t0 = t1
+        runs[tag] = (np.concatenate(parts, 0), eng.scalars.cpu().numpy().copy(), eng.status.cpu().numpy().copy())
+    ref = runs["in_place"]
+    assert (ref[2] == 0).all()
+    for tag in ("registers", "in_place_cut"):
+        got = runs[tag]
+        assert np.array_equal(got[2], ref[2]), tag
+        assert np.array_equal(got[0], ref[0]), "%s: series differ from the one-launch in-place run" % tag
+        assert np.array_equal(got[1], ref[1]), "%s: ponded water / previous precipitation / ending volume / queue rows differ" % tag
+    q = lg.ACC_NAMES.index("giuh_runoff")
+    assert (ref[0][:, :, q] == ref[0][:, :1, q]).all()
+    assert (ref[0][:, 0, q] > 0).sum() > 3  # the fixture routes runoff
+    mixed_mode_check(ref[0][:, 0], g["acc"][:T], T)
