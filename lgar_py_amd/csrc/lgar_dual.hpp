@@ -266,7 +266,58 @@ __device__ __forceinline__ void geff_shared_blocks_w(const LayerK<Dual<double>> 
   // (A software pipeline -- block b's values read before block b+1's node is evaluated and added up after it -- was built
   // and measured: 4 ms SLOWER on the 100 000-column backward pass, 26 more AGPRs of shuffling for latency that is a small
   // part of a block by now.)
-  for (int b = 0; b < nb; b++) {
+  int b = 0;
+#ifndef LGAR_TAN_BLOCKS
+#define LGAR_TAN_BLOCKS 2
+#endif
+  if constexpr (WC != 0 && LGAR_TAN_BLOCKS > 1) {
+    // BL blocks at a time: my nodes of blocks b .. b + BL - 1 are INDEPENDENT chains of ~120 dependent double-precision
+    // operations each, evaluated side by side -- this kernel's wave is alone on its SIMD and a dependent operation issues only
+    // every ~10 cycles, so the other chains run in the gaps of the first.  Heads, node values, the order of every sum:
+    // unchanged (the later blocks' values wait in buffers of their own -- the reduction area, unused until the blocks are done).
+    constexpr int BL = LGAR_TAN_BLOCKS;
+    double *more = xchg + 96 + grp_id * ((BL - 1) * (WC + 1));
+    for (; b + BL <= nb; b += BL) {
+      double hh[BL], K[BL], c1[BL], c2[BL], c3[BL], c4[BL];
+#pragma unroll
+      for (int u = 0; u < BL; u++) {
+        hh[u] = hm;
+#pragma unroll
+        for (int j = 0; j < WC; j++) hm = hm + dh.v;
+      }
+#pragma unroll
+      for (int u = 0; u < BL; u++) node(hh[u], K[u], c1[u], c2[u], c3[u], c4[u]);
+#pragma unroll
+      for (int u = 0; u < BL; u++) {
+        const double jj = (double)(WC * (b + u) + r);
+        s1 += c1[u]; s1j = fma(c1[u], jj, s1j); s2 += c2[u]; s3 += c3[u]; s4 += c4[u];
+      }
+      a1 = c1[BL - 1]; a2 = c2[BL - 1]; a3 = c3[BL - 1]; a4 = c4[BL - 1];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      grp[r] = K[0];
+#pragma unroll
+      for (int u = 1; u < BL; u++) more[(u - 1) * (WC + 1) + r] = K[u];
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      double kq[BL * WC];
+#pragma unroll
+      for (int j = 0; j < WC; j++) {
+        kq[j] = grp[j];
+#pragma unroll
+        for (int u = 1; u < BL; u++) kq[u * WC + j] = more[(u - 1) * (WC + 1) + j];
+      }
+#pragma unroll
+      for (int j = 0; j < BL * WC; j++) {
+        const double pr = k1v + kq[j];
+        gv = gv + (pr * hdh.v);
+        pairsum += pr;
+        k1v = kq[j];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // the next blocks' stores stay behind these loads
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  for (; b < nb; b++) {
     double Kv;
     node(hm, Kv, a1, a2, a3, a4);
     if constexpr (WC != 0) {
