@@ -419,3 +419,39 @@ def test_nan_in_the_forcing_is_flagged():
         pe = np.stack([f[:, 1], g["forcing"][:, 1]], 1)
         e.forward(pr, pe, series=("runoff",))
         assert e.status[0] & 1 and e.status[1] == 0
+
+
+@pytest.mark.parametrize("name", ["rand03", "synth2_phil", "bench_col10707", "five_layer_synth1", "manyfronts_pulse_84"])
+def test_giuh_queue_in_place_survives_cut_launches_and_matches_the_reference_queue(name):
+    """The mixed-precision kernels update the GIUH queue in place in the `scalars` rows of the state (Column::GIUH_MEM) instead of
+    carrying it in registers; the flag "something is queued" is rebuilt from those rows at every launch.  A run cut into four
+    launches must equal the one-launch run bit for bit -- series, scalars, front table --, and at every cut the queue rows must
+    hold the reference's own queue (lgar/giuh.py:8-20; fixtures: `giuh_queue[t]`): to 1e-9 in the native mode, to the
+    mixed-mode flux bar otherwise."""
+    import devsim
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    T = g["forcing"].shape[0]
+    f = g["forcing"]
+    pr, pe = np.repeat(f[:, 0:1], 2, 1), np.repeat(f[:, 1:2], 2, 1)
+    ng = len(g["giuh_ordinates"])
+    cuts = (7, 31, 32, T)
+    for geff_mode, bar in ((1, MIXED_FLUX), (0, 1e-9)):
+        one = _engine(g, 2, search_mode=2, geff_mode=geff_mode)
+        whole = one.forward(pr, pe, series=devsim.ACC_NAMES)
+        cut = _engine(g, 2, search_mode=2, geff_mode=geff_mode)
+        parts, t0 = [], 0
+        scale = max(float(np.abs(g["giuh_queue"]).max()), 1e-6)
+        for t1 in cuts:
+            if t1 <= t0:
+                continue
+            parts.append(cut.forward(pr[t0:t1], pe[t0:t1], series=devsim.ACC_NAMES))
+            q = cut.scalars[3:3 + ng, 0]
+            assert np.abs(q - g["giuh_queue"][t1 - 1]).max() <= bar * scale, (geff_mode, t1)
+            assert (cut.scalars[3 + ng:, 0] == 0).all()
+            t0 = t1
+        for nm in devsim.ACC_NAMES:
+            assert np.array_equal(np.concatenate([p[nm] for p in parts], 0), whole[nm]), (geff_mode, nm)
+        assert np.array_equal(cut.scalars, one.scalars) and np.array_equal(cut.status, one.status)
+        a, b = cut.fronts(), one.fronts()
+        assert all(np.array_equal(a[k], b[k]) for k in a)
+        assert (whole["giuh_runoff"][:, 0] > 0).sum() > 3  # the fixture routes runoff
