@@ -44,7 +44,6 @@ def run_streamed(engine, x, scale=None, pet_scale=None, chunk=512, series=("runo
 
     for b in range(2):
         freed[b].record(main)
-    bounds = [(lo, min(lo + chunk, T)) for lo in range(0, T, chunk)]
     if bounds:
         stage(0, *bounds[0])
     for ci, (lo, hi) in enumerate(bounds):
@@ -206,11 +205,27 @@ def _file_extent(arr):
     return None
 
 
+def chunk_bounds(T, chunk):
+    """[(lo, hi), ...] covering rows 0..T: `chunk` rows at a time, or -- chunk a sequence -- by that SCHEDULE of row counts, whose
+    last entry repeats (a short first chunk starts the kernels after a fraction of a millisecond of copying, long later ones
+    keep the number of launches, each with its ramp-up and tail, small)."""
+    import numpy as np
+    sizes = [int(chunk)] if np.ndim(chunk) == 0 else [int(c) for c in chunk]
+    if not sizes or min(sizes) < 1:
+        raise ValueError("chunk must be a positive row count or a non-empty sequence of them")
+    bounds, lo = [], 0
+    while lo < T:
+        n = sizes[min(len(bounds), len(sizes) - 1)]
+        bounds.append((lo, min(lo + n, T)))
+        lo += n
+    return bounds
+
+
 def run_streamed_columns(engine, precip, pet=None, chunk=256, series=("runoff",), reduce_basin=True, weights=None, check=True,
                          stats=None, reader_threads=8, host_out=None):
     """Integrate engine over a forcing series with N DISTINCT columns that lives on the host -- what a sharded job with real
     per-catchment forcing has (the reference's Data yields ONE basin series row by row, data/Data.py:32-37; run_streamed above
-    is that case).  precip: [T, N] host array (numpy, typically open_forcing_file's memory map; cm/h, float32 or float64);
+    is that case).  chunk: rows per launch, or a schedule of row counts (chunk_bounds).  precip: [T, N] host array (numpy, typically open_forcing_file's memory map; cm/h, float32 or float64);
     pet: the same, or [T] / [T, 1] (one basin series, expanded on the device), or None (zero).
 
     Host -> device, two buffers per stage, every stage overlapping the others:
@@ -240,6 +255,8 @@ def run_streamed_columns(engine, precip, pet=None, chunk=256, series=("runoff",)
     if precip.ndim != 2 or precip.shape[1] != N:
         raise ValueError("precip must be [T, %d]; got %s" % (N, tuple(precip.shape)))
     T = precip.shape[0]
+    bounds = chunk_bounds(T, chunk)  # (chunk: rows per launch, or a schedule of them)
+    chunk = max((hi_ - lo_ for lo_, hi_ in bounds), default=1)  # rows of every staging buffer
     pet_kind = "none" if pet is None else ("full" if (getattr(pet, "ndim", 0) == 2 and pet.shape[1] == N and N != 1) else "basin")
     if pet_kind == "full" and tuple(pet.shape) != (T, N):
         raise ValueError("pet must be [T, N], [T] or None")
@@ -497,7 +514,8 @@ def run_streamed_columns(engine, precip, pet=None, chunk=256, series=("runoff",)
         back_bytes = T * N * len(host_out) * (4 if dt == torch.float32 else 8)
         stats.update(bytes_host_to_device=moved, wall_s=wall, host_to_device_GBps=moved / wall / 1e9,
                      bytes_device_to_host=back_bytes, device_to_host_GBps=back_bytes / wall / 1e9,
-                     column_timesteps_per_s=T * N / wall, chunks=len(bounds), chunk_rows=chunk, reader_threads=nthr,
+                     column_timesteps_per_s=T * N / wall, chunks=len(bounds), chunk_rows=chunk,
+                     chunk_schedule=[h_ - l_ for l_, h_ in bounds], reader_threads=nthr,
                      source="registered map (no staging)" if direct else ("pread into pinned buffers" if all(e is not None for e in extents)
                                                                            else "numpy copies into pinned buffers"),
                      kernel_appetite_GBps_at_1e10=1e10 * 2 * (4 if dt == torch.float32 else 8) / 1e9)

@@ -88,3 +88,26 @@ def test_forcing_csvs_to_mapped_files(tmp_path):
         forcing_csvs_to_files(paths, str(tmp_path / "p2.npy"), str(tmp_path / "e2.npy"))
     # a failed conversion leaves nothing behind: neither partial outputs nor their temporaries
     assert not [f for f in os.listdir(tmp_path) if f.startswith(("p2.npy", "e2.npy"))]
+
+
+def test_chunk_bounds_fixed_size_and_schedule():
+    """pipeline.chunk_bounds: what run_streamed_columns cuts a [T, N] series into -- a fixed row count, or a schedule whose last
+    entry repeats; every row exactly once, in order, no empty chunk."""
+    from lgar_py_amd.pipeline import chunk_bounds
+    assert chunk_bounds(144, 16) == [(lo, lo + 16) for lo in range(0, 144, 16)]
+    assert chunk_bounds(100, 97) == [(0, 97), (97, 100)]
+    assert chunk_bounds(144, (4, 12, 32, 48)) == [(0, 4), (4, 16), (16, 48), (48, 96), (96, 144)]
+    assert chunk_bounds(10, (3,)) == [(0, 3), (3, 6), (6, 9), (9, 10)]
+    assert chunk_bounds(5, (8, 2)) == [(0, 5)]
+    assert chunk_bounds(0, 5) == []
+    rng = np.random.default_rng(1)
+    for _ in range(200):
+        T = int(rng.integers(0, 400))
+        sched = [int(v) for v in rng.integers(1, 60, int(rng.integers(1, 6)))]
+        b = chunk_bounds(T, sched)
+        assert [lo for lo, _ in b] == [0] * (T > 0) + [hi for _, hi in b[:-1]]
+        assert all(hi > lo for lo, hi in b) and (not b or b[-1][1] == T)
+        assert all(hi - lo == sched[min(i, len(sched) - 1)] for i, (lo, hi) in enumerate(b[:-1]))
+    for bad in (0, -3, (), (4, 0)):
+        with pytest.raises(ValueError):
+            chunk_bounds(10, bad)
