@@ -44,6 +44,7 @@ def run_streamed(engine, x, scale=None, pet_scale=None, chunk=512, series=("runo
 
     for b in range(2):
         freed[b].record(main)
+    bounds = [(lo, min(lo + chunk, T)) for lo in range(0, T, chunk)]
     if bounds:
         stage(0, *bounds[0])
     for ci, (lo, hi) in enumerate(bounds):
@@ -225,7 +226,8 @@ def run_streamed_columns(engine, precip, pet=None, chunk=256, series=("runoff",)
                          stats=None, reader_threads=8, host_out=None):
     """Integrate engine over a forcing series with N DISTINCT columns that lives on the host -- what a sharded job with real
     per-catchment forcing has (the reference's Data yields ONE basin series row by row, data/Data.py:32-37; run_streamed above
-    is that case).  chunk: rows per launch, or a schedule of row counts (chunk_bounds).  precip: [T, N] host array (numpy, typically open_forcing_file's memory map; cm/h, float32 or float64);
+    is that case).  chunk: rows per launch, or a schedule of row counts (chunk_bounds).
+    precip: [T, N] host array (numpy, typically open_forcing_file's memory map; cm/h, float32 or float64);
     pet: the same, or [T] / [T, 1] (one basin series, expanded on the device), or None (zero).
 
     Host -> device, two buffers per stage, every stage overlapping the others:
@@ -287,7 +289,6 @@ def run_streamed_columns(engine, precip, pet=None, chunk=256, series=("runoff",)
     ready = [torch.cuda.Event(), torch.cuda.Event()]   # device buffer b holds its chunk
     freed = [torch.cuda.Event(), torch.cuda.Event()]   # the kernels that read device buffer b have finished
     landed = [torch.cuda.Event(), torch.cuda.Event()]  # the D2H copies out of output buffer b have finished
-    bounds = [(lo, min(lo + chunk, T)) for lo in range(0, T, chunk)]
     filled = queue.Queue(maxsize=1)  # chunk indices whose pinned buffer is full
     enqueued = [threading.Event() for _ in bounds]  # the H2D copy of chunk ci has been put on the side stream
     err = []
