@@ -688,9 +688,8 @@ def main():
                         for _ in range(3):
                             es.reset()
                             st_ = {}
-                            res_ = run_streamed_columns(es, src, None, chunk=chunk, series=("runoff",), check=False, stats=st_,
-                                                        reader_threads=threads, **kw)
-                            st_["_basin_runoff"] = res_["runoff"]
+                            run_streamed_columns(es, src, None, chunk=chunk, series=("runoff",), check=False, stats=st_,
+                                                 reader_threads=threads, **kw)
                             if best_ is None or st_["wall_s"] < best_["wall_s"]:
                                 best_ = st_
                         return best_
@@ -701,16 +700,6 @@ def main():
                     rm = open_forcing_file(path, register=True)        # the map registered with the runtime: no staging copy
                     t_reg_in = time.perf_counter() - t_reg_in
                     best = leg(rm, threads=1)
-                    # ... and by a chunk SCHEDULE (4, 12, 32, 48, 48 rows: the kernels start after 0.3 ms of copying instead of
-                    # 1.2, five launches instead of nine).  Reported beside the fixed-chunk figure, checked against it; added at
-                    # the end of round 5 without a GPU run of its own, hence guarded on its own.
-                    try:
-                        sch = leg(rm, threads=1, chunk=(4, 12, 32, 48))
-                        schedule_rec = {"value": sch["column_timesteps_per_s"], "wall_ms": 1e3 * sch["wall_s"],
-                                        "host_to_device_GBps": sch["host_to_device_GBps"], "chunk_schedule": sch["chunk_schedule"],
-                                        "basin_runoff_equals_fixed_chunks": bool(torch.equal(sch["_basin_runoff"], best["_basin_runoff"]))}
-                    except Exception as e:  # noqa: BLE001
-                        schedule_rec = {"error": "%s: %s" % (type(e).__name__, e)}
                     create_forcing_file(opath, (Ts, Ns), "float32")
                     t_reg = time.perf_counter()
                     om = open_forcing_file(opath, register=True)
@@ -730,7 +719,6 @@ def main():
                     "wall_ms": 1e3 * best["wall_s"], "columns": Ns, "timesteps": Ts, "chunk_rows": best["chunk_rows"],
                     "source": best["source"], "register_ms": 1e3 * t_reg_in, "dtype": "f32",
                     "kernel_appetite_GBps_at_1e10": best["kernel_appetite_GBps_at_1e10"],
-                    "chunk_schedule": schedule_rec,
                     "pread_staging": {
                         "value": staged["column_timesteps_per_s"], "wall_ms": 1e3 * staged["wall_s"],
                         "host_to_device_GBps": staged["host_to_device_GBps"], "reader_threads": staged["reader_threads"],
